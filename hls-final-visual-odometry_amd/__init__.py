@@ -1,0 +1,394 @@
+"""viso-hip: MI355X-native feature detection + matching behind the libviso2
+`Matcher` surface of Chang-Tun-Yu/HLS-final-Visual-Odometry.
+
+This package is the thin Python host mirror over the C ABI of
+`libviso_hip.so` (include/viso_hip.h).  All compute happens in the hand-written
+HIP kernels under csrc/; there is no CPU or PyTorch fallback: importing works
+without a GPU (so the library and its exported symbols can be checked), any
+compute call without a usable GPU raises `VisoHipError(VH_ERR_NO_DEVICE)`, and a
+missing shared library raises at import.
+
+The directory name contains hyphens, so load it with
+`__graft_entry__.load_package()` (importlib under the name
+`hls_final_visual_odometry_amd`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import synth  # noqa: F401  (synthetic KITTI-shaped frames)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libviso_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
+
+VH_OK = 0
+VH_ERR_INVALID_ARG, VH_ERR_NO_DEVICE, VH_ERR_HIP, VH_ERR_CAPACITY, VH_ERR_UNSUPPORTED, VH_ERR_STATE = -1, -2, -3, -4, -5, -6
+SET_1P, SET_2P, SET_1C, SET_2C = 0, 1, 2, 3
+METHOD_FLOW, METHOD_STEREO, METHOD_QUAD = 0, 1, 2
+
+#: every symbol include/viso_hip.h declares (checked by the CPU test-suite)
+ABI_SYMBOLS = (
+    "vh_abi_version", "vh_device_count", "vh_error_string", "vh_last_error", "vh_default_params",
+    "vh_create", "vh_create_ex", "vh_destroy", "vh_set_intrinsics", "vh_push_back", "vh_push_back_device",
+    "vh_match_features", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
+    "vh_set_stream", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match",
+    "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_push_back_device",
+    "vh_group_push_back", "vh_group_match_features", "vh_group_get_matches", "vh_group_get_features",
+    "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
+    "vh_group_profile_read", "vh_group_profile_reset",
+)
+
+
+class Params(C.Structure):
+    """POD mirror of Matcher::parameters (reference src/matcher.h:45-72)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "nms_n", "nms_tau", "match_binsize", "match_radius", "match_disp_tolerance",
+        "outlier_disp_tolerance", "outlier_flow_tolerance", "multi_stage",
+        "half_resolution", "refinement")] + [(n, C.c_double) for n in ("f", "cu", "cv", "base")]
+
+    @classmethod
+    def default(cls, **kw):
+        """Matcher::parameters() defaults (reference src/matcher.h:60-71)."""
+        p = cls(nms_n=2, nms_tau=50, match_binsize=50, match_radius=200,
+                match_disp_tolerance=2, outlier_disp_tolerance=5, outlier_flow_tolerance=5,
+                multi_stage=0, half_resolution=0, refinement=0)
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+
+#: Matcher::p_match (reference src/matcher.h:89-104), 48 bytes
+P_MATCH_DTYPE = np.dtype([
+    ("u1p", "<f4"), ("v1p", "<f4"), ("i1p", "<i4"),
+    ("u2p", "<f4"), ("v2p", "<f4"), ("i2p", "<i4"),
+    ("u1c", "<f4"), ("v1c", "<f4"), ("i1c", "<i4"),
+    ("u2c", "<f4"), ("v2c", "<f4"), ("i2c", "<i4")])
+
+
+class VisoHipError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        msg = _lib().vh_error_string(code).decode()
+        last = _lib().vh_last_error().decode()
+        super().__init__(f"{where}: {msg} ({code})" + (f" [{last}]" if last else ""))
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into libviso_hip.so (in-tree)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the HIP path)")
+        lib = C.CDLL(LIB_PATH)
+        lib.vh_error_string.restype = C.c_char_p
+        lib.vh_error_string.argtypes = [C.c_int32]
+        lib.vh_last_error.restype = C.c_char_p
+        vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+        sig = {
+            "vh_create": [vp, i32, vp], "vh_create_ex": [vp, i32, i32, i32, vp], "vh_destroy": [vp],
+            "vh_set_intrinsics": [vp, f64, f64, f64, f64],
+            "vh_push_back": [vp, vp, vp, vp, i32], "vh_push_back_device": [vp, vp, vp, vp, i32],
+            "vh_match_features": [vp, i32, vp], "vh_bucket_features": [vp, i32, f32, f32],
+            "vh_get_matches": [vp, vp, i32, vp], "vh_get_features": [vp, i32, vp, i32, vp],
+            "vh_synchronize": [vp], "vh_set_stream": [vp, vp],
+            "vh_compute_features": [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp],
+            "vh_filters": [i32, vp, i32, i32, vp, vp, vp, vp],
+            "vh_create_index": [vp, i32, vp, vp, i32, vp, vp],
+            "vh_match_all": [vp, i32, vp, vp, i32, vp, i32, i32, vp],
+            "vh_match": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
+            "vh_group_create": [vp, i32, i32, i32, i32, vp], "vh_group_destroy": [vp], "vh_group_streams": [vp],
+            "vh_group_push_back_device": [vp, vp, vp, i64, vp, i32],
+            "vh_group_push_back": [vp, vp, vp, i64, vp, i32],
+            "vh_group_match_features": [vp, i32], "vh_group_get_matches": [vp, i32, vp, i32, vp],
+            "vh_group_get_features": [vp, i32, i32, vp, i32, vp], "vh_group_get_counts": [vp, vp, vp],
+            "vh_group_synchronize": [vp], "vh_group_set_stream": [vp, vp],
+            "vh_group_profile_enable": [vp, i32], "vh_group_profile_read": [vp, C.c_char_p, vp, vp],
+            "vh_group_profile_reset": [vp],
+        }
+        for name, args in sig.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = None if name.endswith("destroy") else i32
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc: int, where: str, allow=()):
+    if rc != VH_OK and rc not in allow:
+        raise VisoHipError(rc, where)
+    return rc
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dims(dims):
+    return (C.c_int32 * 3)(*[int(d) for d in dims])
+
+
+def _feat(m):
+    if m is None:
+        return np.zeros((0, 12), np.int32), 0
+    m = np.ascontiguousarray(m, dtype=np.int32).reshape(-1, 12)
+    return m, m.shape[0]
+
+
+def device_count() -> int:
+    """Visible HIP devices (0 when there is none)."""
+    return max(0, _lib().vh_device_count())
+
+
+def abi_version() -> int:
+    return _lib().vh_abi_version()
+
+
+# --------------------------------------------------------------------------- one stream
+class Matcher:
+    """Host mirror of the reference's `Matcher` public surface
+    (src/matcher.h:75-143): pushBack / matchFeatures / bucketFeatures /
+    getMatches, same argument meaning, plus getFeatures for the parity checks."""
+
+    def __init__(self, param: Params | None = None, device: int = 0, max_features: int = 0,
+                 max_matches: int = 0):
+        self.param = param if param is not None else Params.default()
+        h = C.c_void_p()
+        _check(_lib().vh_create_ex(C.byref(self.param), device, max_features, max_matches, C.byref(h)), "vh_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().vh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def setIntrinsics(self, f, cu, cv, base):
+        _check(_lib().vh_set_intrinsics(self._h, f, cu, cv, base), "vh_set_intrinsics")
+
+    def pushBack(self, I1, I2=None, dims=None, replace=False):
+        """I1/I2: (H, bpl) uint8 numpy arrays (host) -- Matcher::pushBack (src/matcher.cpp:51-91).
+        Like the reference, a dimension mismatch is reported and the call returns False."""
+        I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+        if I2 is not None:
+            I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+        if dims is None:
+            dims = [I1.shape[1], I1.shape[0], I1.shape[1]]
+        rc = _lib().vh_push_back(self._h, _ptr(I1), _ptr(I2), _dims(dims), 1 if replace else 0)
+        if rc == VH_ERR_INVALID_ARG:
+            print("ERROR: Image dimension mismatch!")
+            return False
+        _check(rc, "vh_push_back")
+        return True
+
+    def pushBackDevice(self, ptr1: int, ptr2: int | None, dims, replace=False):
+        _check(_lib().vh_push_back_device(self._h, C.c_void_p(ptr1), C.c_void_p(ptr2) if ptr2 else None,
+                                          _dims(dims), 1 if replace else 0), "vh_push_back_device")
+
+    def matchFeatures(self, method: int, Tr_delta=None):
+        tr = None
+        if Tr_delta is not None:
+            tr = np.ascontiguousarray(Tr_delta, dtype=np.float64).reshape(16)
+        _check(_lib().vh_match_features(self._h, int(method), _ptr(tr)), "vh_match_features")
+
+    def bucketFeatures(self, max_features: int, bucket_width: float, bucket_height: float):
+        _check(_lib().vh_bucket_features(self._h, int(max_features), float(bucket_width), float(bucket_height)),
+               "vh_bucket_features")
+
+    def getMatches(self) -> np.ndarray:
+        n = C.c_int32(0)
+        _check(_lib().vh_get_matches(self._h, None, 0, C.byref(n)), "vh_get_matches", allow=(VH_ERR_CAPACITY,))
+        out = np.zeros(n.value, P_MATCH_DTYPE)
+        if n.value:
+            _check(_lib().vh_get_matches(self._h, _ptr(out), n.value, C.byref(n)), "vh_get_matches")
+        return out
+
+    def getFeatures(self, which: int) -> np.ndarray:
+        n = C.c_int32(0)
+        _check(_lib().vh_get_features(self._h, which, None, 0, C.byref(n)), "vh_get_features", allow=(VH_ERR_CAPACITY,))
+        out = np.zeros((n.value, 12), np.int32)
+        if n.value:
+            _check(_lib().vh_get_features(self._h, which, _ptr(out), n.value, C.byref(n)), "vh_get_features")
+        return out
+
+    def synchronize(self):
+        _check(_lib().vh_synchronize(self._h), "vh_synchronize")
+
+    def setStream(self, hip_stream: int | None):
+        _check(_lib().vh_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None), "vh_set_stream")
+
+
+# ------------------------------------------------------------------ S streams in lock step
+class StreamGroup:
+    """S independent camera streams stepped together (vh_group_*): the
+    multi-stream configuration, one sequence per stream, no exchange between
+    streams.  Images are device pointers (e.g. torch `tensor.data_ptr()`)."""
+
+    def __init__(self, n_streams: int, param: Params | None = None, device: int = 0,
+                 max_features: int = 0, max_matches: int = 0):
+        self.param = param if param is not None else Params.default()
+        self.S = int(n_streams)
+        h = C.c_void_p()
+        _check(_lib().vh_group_create(C.byref(self.param), device, self.S, max_features, max_matches, C.byref(h)),
+               "vh_group_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().vh_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def pushBackDevice(self, ptr1: int, ptr2: int | None, stride_bytes: int, dims, replace=False):
+        _check(_lib().vh_group_push_back_device(self._h, C.c_void_p(ptr1), C.c_void_p(ptr2) if ptr2 else None,
+                                                int(stride_bytes), _dims(dims), 1 if replace else 0),
+               "vh_group_push_back_device")
+
+    def pushBack(self, I1, I2=None, dims=None, replace=False):
+        """I1/I2: (S, H, bpl) uint8 numpy arrays."""
+        I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+        assert I1.ndim == 3 and I1.shape[0] == self.S
+        if I2 is not None:
+            I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+        if dims is None:
+            dims = [I1.shape[2], I1.shape[1], I1.shape[2]]
+        _check(_lib().vh_group_push_back(self._h, _ptr(I1), _ptr(I2), I1.shape[1] * I1.shape[2], _dims(dims),
+                                         1 if replace else 0), "vh_group_push_back")
+
+    def matchFeatures(self, method: int):
+        _check(_lib().vh_group_match_features(self._h, int(method)), "vh_group_match_features")
+
+    def getMatches(self, stream: int) -> np.ndarray:
+        n = C.c_int32(0)
+        _check(_lib().vh_group_get_matches(self._h, stream, None, 0, C.byref(n)), "vh_group_get_matches",
+               allow=(VH_ERR_CAPACITY,))
+        out = np.zeros(n.value, P_MATCH_DTYPE)
+        if n.value:
+            _check(_lib().vh_group_get_matches(self._h, stream, _ptr(out), n.value, C.byref(n)), "vh_group_get_matches")
+        return out
+
+    def getFeatures(self, stream: int, which: int) -> np.ndarray:
+        n = C.c_int32(0)
+        _check(_lib().vh_group_get_features(self._h, stream, which, None, 0, C.byref(n)), "vh_group_get_features",
+               allow=(VH_ERR_CAPACITY,))
+        out = np.zeros((n.value, 12), np.int32)
+        if n.value:
+            _check(_lib().vh_group_get_features(self._h, stream, which, _ptr(out), n.value, C.byref(n)),
+                   "vh_group_get_features")
+        return out
+
+    def getCounts(self):
+        nf = np.zeros((self.S, 4), np.int32)
+        nm = np.zeros(self.S, np.int32)
+        _check(_lib().vh_group_get_counts(self._h, _ptr(nf), _ptr(nm)), "vh_group_get_counts")
+        return nf, nm
+
+    def synchronize(self):
+        _check(_lib().vh_group_synchronize(self._h), "vh_group_synchronize")
+
+    def setStream(self, hip_stream: int | None):
+        _check(_lib().vh_group_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None),
+               "vh_group_set_stream")
+
+    def profileEnable(self, on: bool = True):
+        _check(_lib().vh_group_profile_enable(self._h, 1 if on else 0), "vh_group_profile_enable")
+
+    def profileReset(self):
+        _check(_lib().vh_group_profile_reset(self._h), "vh_group_profile_reset")
+
+    def profileRead(self, name: str):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        _check(_lib().vh_group_profile_read(self._h, name.encode(), C.byref(ms), C.byref(n)), "vh_group_profile_read")
+        return ms.value, n.value
+
+
+# ------------------------------------------------------------------ stateless primitives
+def compute_features(param: Params, img, dims, device: int = 0, planes: bool = False, cap: int | None = None):
+    """Matcher::computeFeatures (reference src/matcher.cpp:585-672) ->
+    (max1 [n1,12], max2 [n2,12][, I_du, I_dv])."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if cap is None:
+        cap = 4 * (dims[0] // (param.nms_n + 1) + 1) * (dims[1] // (param.nms_n + 1) + 1)
+    m1 = np.zeros((cap, 12), np.int32)
+    m2 = np.zeros((cap, 12), np.int32)
+    n1, n2 = C.c_int32(0), C.c_int32(0)
+    du = dv = None
+    if planes:
+        if param.half_resolution:
+            w2 = dims[0] // 2
+            shape = (dims[1] // 2, w2 + 15 - (w2 - 1) % 16)
+        else:
+            shape = (dims[1], dims[2])
+        du = np.zeros(shape, np.uint8)
+        dv = np.zeros(shape, np.uint8)
+    _check(_lib().vh_compute_features(C.byref(param), device, _ptr(img), _dims(dims), _ptr(m1), cap, C.byref(n1),
+                                      _ptr(m2), cap, C.byref(n2), _ptr(du), _ptr(dv)), "vh_compute_features")
+    r = (m1[:n1.value].copy(), m2[:n2.value].copy())
+    return r + (du, dv) if planes else r
+
+
+def filters(img, device: int = 0):
+    """sobel5x5 / blob5x5 / checkerboard5x5 (reference src/filter.h:80-96) on
+    the valid interior -> (du, dv, f1, f2)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, bpl = img.shape
+    du = np.empty((h, bpl), np.uint8); dv = np.empty((h, bpl), np.uint8)
+    f1 = np.empty((h, bpl), np.int16); f2 = np.empty((h, bpl), np.int16)
+    _check(_lib().vh_filters(device, _ptr(img), bpl, h, _ptr(du), _ptr(dv), _ptr(f1), _ptr(f2)), "vh_filters")
+    return du, dv, f1, f2
+
+
+def create_index(param: Params, dims, m, device: int = 0):
+    """Matcher::createIndexVector (reference src/matcher.cpp:194-214) as CSR."""
+    m, n = _feat(m)
+    ubn = -(-int(dims[0]) // param.match_binsize)
+    vbn = -(-int(dims[1]) // param.match_binsize)
+    bs = np.zeros(4 * ubn * vbn + 1, np.int32)
+    lst = np.zeros(max(n, 1), np.int32)
+    _check(_lib().vh_create_index(C.byref(param), device, _dims(dims), _ptr(m), n, _ptr(bs), _ptr(lst)), "vh_create_index")
+    return bs, lst[:n]
+
+
+def match_all(param: Params, dims, m1, m2, flow: bool = True, device: int = 0):
+    """Matcher::findMatch (reference src/matcher.cpp:216-272) for every query."""
+    m1, n1 = _feat(m1)
+    m2, n2 = _feat(m2)
+    best = np.zeros(max(n1, 1), np.int32)
+    _check(_lib().vh_match_all(C.byref(param), device, _dims(dims), _ptr(m1), n1, _ptr(m2), n2, 1 if flow else 0,
+                               _ptr(best)), "vh_match_all")
+    return best[:n1]
+
+
+def match(param: Params, dims, method: int, m1p=None, m2p=None, m1c=None, m2c=None, device: int = 0, cap=None):
+    """Matcher::matching (reference src/matcher.cpp:274-344) on given feature arrays."""
+    sets = [_feat(m) for m in (m1p, m2p, m1c, m2c)]
+    if cap is None:
+        cap = max(s[1] for s in sets) + 1
+    out = np.zeros(cap, P_MATCH_DTYPE)
+    n = C.c_int32(0)
+    _check(_lib().vh_match(C.byref(param), device, _dims(dims), int(method),
+                           _ptr(sets[0][0]), sets[0][1], _ptr(sets[1][0]), sets[1][1],
+                           _ptr(sets[2][0]), sets[2][1], _ptr(sets[3][0]), sets[3][1],
+                           _ptr(out), cap, C.byref(n)), "vh_match")
+    return out[:n.value].copy()

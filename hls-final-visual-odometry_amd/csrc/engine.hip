@@ -1,0 +1,737 @@
+// engine.hip -- host side of libviso_hip.so: device memory, launch sequencing
+// and the extern "C" ABI declared in include/viso_hip.h.
+//
+// A vh_group owns S independent camera streams that are stepped together; a
+// vh_matcher is a group of one.  The reference's Matcher state (ring buffer of
+// two feature-set pairs, src/matcher.h:245-259) lives in HBM and rotates by
+// flipping `pair_cur`; nothing is copied on pushBack.
+#include "vh_dev.h"
+#include "../../include/viso_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string t_last_error;
+
+#define VH_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      t_last_error = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      return VH_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+int32_t round_up(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
+
+struct ProfEntry {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms = 0;
+  int64_t launches = 0;
+};
+
+struct Group {
+  vh_params p{};
+  int32_t device = 0, S = 1;
+  int32_t req_features = 0, req_matches = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+
+  bool allocated = false;
+  int32_t dims[3] = {0, 0, 0};
+  VhGeom g{};
+  VhSets sets{};
+  int32_t cap = 0, mcap = 0;
+  int32_t pair_cur = 0;
+  int64_t frames = 0;
+
+  uint8_t *d_stage[2] = {nullptr, nullptr};  // host-image staging, S images each
+  size_t stage_bytes = 0;
+  uint8_t *d_half = nullptr;                 // half-resolution images [S*2]
+  uint64_t *d_rec = nullptr;
+  int32_t *d_chunk_count = nullptr;
+  int32_t *d_best = nullptr;
+  int4 *d_chain = nullptr;
+  uint32_t *d_mask = nullptr;
+  uint32_t epoch = 0;
+  void *d_matches = nullptr;
+  int32_t *d_match_count = nullptr;
+  std::vector<void *> allocs;
+
+  int32_t last_method = -1;
+  bool bucketed = false;
+  std::vector<vh_p_match> host_matches;  // stream 0 only, after vh_bucket_features
+
+  bool prof = false;
+  std::map<std::string, ProfEntry> prof_entries;
+
+  ~Group() { release(); if (own_stream) hipStreamDestroy(own_stream); }
+
+  void release() {
+    for (void *q : allocs) hipFree(q);
+    allocs.clear();
+    d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0;
+    d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
+    d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr;
+    allocated = false;
+  }
+
+  template <class T> int32_t dmalloc(T **out, size_t count, bool zero) {
+    void *q = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    VH_HIP(hipMalloc(&q, bytes));
+    allocs.push_back(q);
+    if (zero) VH_HIP(hipMemsetAsync(q, 0, bytes, stream));
+    *out = (T *)q;
+    return VH_OK;
+  }
+
+  // ---- geometry ----------------------------------------------------------
+  static int32_t block_count(int32_t extent, int32_t n) {
+    // for (i=n+margin; i<extent-n-margin; i+=n+1)   (matcher.cpp:381-382)
+    const int32_t lo = n + VH_MARGIN, hi = extent - n - VH_MARGIN;
+    return hi > lo ? (hi - lo + n) / (n + 1) : 0;
+  }
+
+  int32_t setup_geometry(const int32_t d[3]) {
+    g = VhGeom{};
+    g.W = d[0]; g.H = d[1]; g.bpl = d[2];
+    if (p.half_resolution) {  // getHalfResolutionDimensions, matcher.cpp:566-570
+      g.Wm = d[0] / 2; g.Hm = d[1] / 2;
+      g.bplm = g.Wm > 0 ? g.Wm + 15 - (g.Wm - 1) % 16 : 16;
+      g.scale = 2;
+    } else {
+      g.Wm = d[0]; g.Hm = d[1]; g.bplm = d[2]; g.scale = 1;
+    }
+    g.n = p.nms_n; g.tau = p.nms_tau;
+    g.nbx = block_count(g.Wm, g.n); g.nby = block_count(g.Hm, g.n);
+    if (g.nbx == 0 || g.nby == 0) g.nbx = g.nby = 0;
+    g.nblocks = g.nbx * g.nby;
+    g.nchunks = std::max(1, (g.nblocks + VH_CHUNK - 1) / VH_CHUNK);
+    static const int32_t cand[][2] = {{32, 8}, {16, 8}, {16, 4}, {8, 4}, {4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+    for (auto &c : cand) {
+      g.tbx = c[0]; g.tby = c[1];
+      g.FW = g.tbx * (g.n + 1) + 2 * g.n; g.FH = g.tby * (g.n + 1) + 2 * g.n;
+      g.IW = g.FW + 4; g.IH = g.FH + 4;
+      g.IWp = round_up(g.IW, 4); g.FWp = g.FW;
+      const size_t lds = (size_t)g.IH * g.IWp + 4 * (size_t)g.FH * g.FWp;
+      if (lds <= 60 * 1024) return VH_OK;
+    }
+    return VH_ERR_UNSUPPORTED;
+  }
+
+  int32_t ensure(const int32_t d[3]) {
+    if (allocated && d[0] == dims[0] && d[1] == dims[1] && d[2] == dims[2]) return VH_OK;
+    if (allocated) { VH_HIP(hipStreamSynchronize(stream)); release(); }
+    if (d[0] <= 0 || d[1] <= 0 || d[2] < d[0]) return VH_ERR_INVALID_ARG;
+    if (d[0] > 16384 || d[1] > 16384) return VH_ERR_UNSUPPORTED;
+    int32_t rc = setup_geometry(d);
+    if (rc != VH_OK) return rc;
+    dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
+    int64_t c = req_features > 0 ? req_features : std::max<int64_t>(4 * (int64_t)g.nblocks, 64);
+    if (c > (1 << 20) - 1) c = (1 << 20) - 1;
+    cap = (int32_t)c;
+    mcap = req_matches > 0 ? req_matches : cap;
+
+    sets = VhSets{};
+    sets.cap = cap;
+    sets.binsize = p.match_binsize;
+    sets.ubn = (dims[0] + p.match_binsize - 1) / p.match_binsize;  // ceil(W/binsize), matcher.cpp:282-283
+    sets.vbn = (dims[1] + p.match_binsize - 1) / p.match_binsize;
+    sets.nbins = 4 * sets.ubn * sets.vbn;
+    sets.max_tiles = cap / 64 + 4 * sets.ubn + 1;
+    sets.W = dims[0]; sets.H = dims[1];
+    const size_t ns = 4 * (size_t)S;
+    if ((rc = dmalloc(&sets.feat, ns * cap * 12, false))) return rc;
+    if ((rc = dmalloc(&sets.s_uv, ns * cap, false))) return rc;
+    if ((rc = dmalloc(&sets.s_idx, ns * cap, false))) return rc;
+    if ((rc = dmalloc(&sets.s_desc, ns * cap * 8, false))) return rc;
+    if ((rc = dmalloc(&sets.bin_start, ns * (sets.nbins + 1), true))) return rc;
+    if ((rc = dmalloc(&sets.hist, ns * sets.nbins, true))) return rc;
+    if ((rc = dmalloc(&sets.cursor, ns * sets.nbins, true))) return rc;
+    if ((rc = dmalloc(&sets.tmp_idx, ns * cap, false))) return rc;
+    if ((rc = dmalloc(&sets.count, ns, true))) return rc;
+    if ((rc = dmalloc(&sets.tiles, ns * sets.max_tiles, false))) return rc;
+    if ((rc = dmalloc(&sets.tile_cnt, ns, true))) return rc;
+    if ((rc = dmalloc(&d_rec, 2 * (size_t)S * std::max(g.nblocks, 1), false))) return rc;
+    if ((rc = dmalloc(&d_chunk_count, 2 * (size_t)S * g.nchunks, true))) return rc;
+    if ((rc = dmalloc(&d_best, 4 * (size_t)S * cap, false))) return rc;
+    if ((rc = dmalloc(&d_chain, (size_t)S * cap, false))) return rc;
+    if ((rc = dmalloc((uint8_t **)&d_matches, (size_t)S * mcap * sizeof(vh_p_match), false))) return rc;
+    if ((rc = dmalloc(&d_match_count, (size_t)S, true))) return rc;
+    if (p.half_resolution)
+      if ((rc = dmalloc(&d_half, 2 * (size_t)S * g.bplm * g.Hm, false))) return rc;
+    allocated = true;
+    pair_cur = 0; frames = 0; epoch = 0; last_method = -1; bucketed = false;
+    return VH_OK;
+  }
+
+  // ---- profiling ---------------------------------------------------------
+  struct Scope {
+    Group *gq; const char *name; hipEvent_t e0 = nullptr, e1 = nullptr;
+    Scope(Group *gq_, const char *n) : gq(gq_), name(n) {
+      if (gq->prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, gq->stream); }
+    }
+    ~Scope() {
+      if (gq->prof) { hipEventRecord(e1, gq->stream); gq->prof_entries[name].pending.emplace_back(e0, e1); }
+    }
+  };
+  void prof_collect() {
+    for (auto &kv : prof_entries) {
+      for (auto &pr : kv.second.pending) {
+        float ms = 0;
+        hipEventSynchronize(pr.second);
+        hipEventElapsedTime(&ms, pr.first, pr.second);
+        kv.second.ms += ms; kv.second.launches++;
+        hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+      }
+      kv.second.pending.clear();
+    }
+  }
+
+  // ---- detect + bin ------------------------------------------------------
+  int32_t bin_sets(int32_t set0, int32_t nsets, bool zero_first) {
+    if (zero_first) {
+      VH_HIP(hipMemsetAsync(sets.hist + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
+      VH_HIP(hipMemsetAsync(sets.cursor + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
+    }
+    { Scope sc(this, "bin_hist"); vh_launch_bin_hist(sets, set0, nsets, stream); }
+    { Scope sc(this, "bin_scan"); vh_launch_bin_scan(sets, set0, nsets, stream); }
+    { Scope sc(this, "bin_fill"); vh_launch_bin_fill(sets, set0, nsets, stream); }
+    { Scope sc(this, "bin_sort"); vh_launch_bin_sort(sets, set0, nsets, stream); }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+  }
+
+  int32_t push_device(const void *dI1, const void *dI2, int64_t stride, const int32_t d[3], int32_t replace) {
+    if (!dI1 || !d) return VH_ERR_INVALID_ARG;
+    int32_t rc = ensure(d);
+    if (rc != VH_OK) return rc;
+    if (!replace && frames > 0) pair_cur ^= 1;  // ring buffer shift (matcher.cpp:64-79)
+    frames++;
+    bucketed = false; last_method = -1;
+    const int32_t set0 = pair_cur * 2 * S, nsets = 2 * S;
+    VH_HIP(hipMemsetAsync(sets.count + set0, 0, sizeof(int32_t) * nsets, stream));
+    VH_HIP(hipMemsetAsync(d_chunk_count, 0, sizeof(int32_t) * 2 * (size_t)S * g.nchunks, stream));
+    VhImages im{};
+    im.base[0] = (const uint8_t *)dI1; im.base[1] = (const uint8_t *)dI2;
+    im.stride = stride; im.ncam = dI2 ? 2 : 1; im.S = S; im.pair_cur = pair_cur;
+    if (p.half_resolution) {
+      { Scope sc(this, "half_res"); vh_launch_half_res(im, d_half, g, stream); }
+      // half images are stored by image id; present them as one "camera" with unit stride
+      VhImages hm = im;
+      const int64_t isz = (int64_t)g.bplm * g.Hm;
+      hm.base[0] = d_half; hm.base[1] = d_half + isz; hm.stride = isz * im.ncam;
+      im = hm;
+    }
+    { Scope sc(this, "detect_nms"); vh_launch_detect_nms(im, g, d_rec, d_chunk_count, stream); }
+    { Scope sc(this, "emit_features"); vh_launch_emit_features(im, g, d_rec, d_chunk_count, sets.feat, sets.count, cap, stream); }
+    VH_HIP(hipGetLastError());
+    return bin_sets(set0, nsets, true);
+  }
+
+  int32_t push_host(const uint8_t *I1, const uint8_t *I2, int64_t stride, const int32_t d[3], int32_t replace) {
+    if (!I1 || !d) return VH_ERR_INVALID_ARG;
+    int32_t rc = ensure(d);
+    if (rc != VH_OK) return rc;
+    const size_t isz = (size_t)d[2] * d[1];
+    if (stage_bytes < isz * S) {
+      for (int k = 0; k < 2; k++) if ((rc = dmalloc(&d_stage[k], isz * S, false))) return rc;
+      stage_bytes = isz * S;
+    }
+    for (int k = 0; k < 2; k++) {
+      const uint8_t *src = k ? I2 : I1;
+      if (!src) continue;
+      for (int32_t s = 0; s < S; s++)
+        VH_HIP(hipMemcpyAsync(d_stage[k] + isz * s, src + stride * s, isz, hipMemcpyHostToDevice, stream));
+    }
+    // the images are only borrowed for the duration of the call (demo.cpp:250-251)
+    VH_HIP(hipStreamSynchronize(stream));
+    return push_device(d_stage[0], I2 ? d_stage[1] : nullptr, (int64_t)isz, d, replace);
+  }
+
+  // ---- match ---------------------------------------------------------------
+  VhMatchArgs match_args(int32_t method) const {
+    VhMatchArgs a{};
+    a.S = S; a.pair_cur = pair_cur; a.radius = p.match_radius; a.disp_tol = p.match_disp_tolerance;
+    if (method == VH_METHOD_FLOW) {  // matcher.cpp:320-321
+      a.npass = 2; a.pass[0] = {VH_SET_1C, VH_SET_1P, 1}; a.pass[1] = {VH_SET_1P, VH_SET_1C, 1};
+    } else if (method == VH_METHOD_STEREO) {
+      a.npass = 2; a.pass[0] = {VH_SET_1C, VH_SET_2C, 0}; a.pass[1] = {VH_SET_2C, VH_SET_1C, 0};
+    } else {
+      a.npass = 4;
+      a.pass[0] = {VH_SET_1P, VH_SET_2P, 0}; a.pass[1] = {VH_SET_2P, VH_SET_2C, 1};
+      a.pass[2] = {VH_SET_2C, VH_SET_1C, 0}; a.pass[3] = {VH_SET_1C, VH_SET_1P, 1};
+    }
+    return a;
+  }
+
+  int32_t match(int32_t method) {
+    if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
+    if (!allocated) return VH_ERR_STATE;
+    const VhMatchArgs a = match_args(method);
+    if (method == VH_METHOD_FLOW) {
+      if (!d_mask) { int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], true); if (rc) return rc; epoch = 0; }
+      if (++epoch >= 4095) {
+        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], stream));
+        epoch = 1;
+      }
+    }
+    { Scope sc(this, "match"); vh_launch_match(sets, a, d_best, stream); }
+    { Scope sc(this, "chain"); vh_launch_chain(sets, a, method, d_best, d_chain, d_mask, epoch, stream); }
+    { Scope sc(this, "emit_matches"); vh_launch_emit_matches(sets, a, method, d_chain, d_mask, epoch, d_matches, mcap, d_match_count, stream); }
+    VH_HIP(hipGetLastError());
+    last_method = method; bucketed = false;
+    return VH_OK;
+  }
+
+  int32_t get_matches(int32_t s, vh_p_match *out, int32_t capo, int32_t *n) {
+    if (!n || s < 0 || s >= S || capo < 0 || (capo > 0 && !out)) return VH_ERR_INVALID_ARG;
+    *n = 0;
+    if (!allocated || last_method < 0) return VH_OK;
+    if (bucketed && s == 0) {
+      *n = (int32_t)host_matches.size();
+      const int32_t k = std::min(*n, capo);
+      if (k) memcpy(out, host_matches.data(), sizeof(vh_p_match) * (size_t)k);
+      return *n > capo ? VH_ERR_CAPACITY : VH_OK;
+    }
+    int32_t cnt = 0;
+    VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    VH_HIP(hipStreamSynchronize(stream));
+    *n = cnt;
+    const int32_t k = std::min(std::min(cnt, mcap), capo);
+    if (k > 0) {
+      VH_HIP(hipMemcpyAsync(out, (const uint8_t *)d_matches + (size_t)s * mcap * sizeof(vh_p_match),
+                            sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, stream));
+      VH_HIP(hipStreamSynchronize(stream));
+    }
+    return (cnt > capo || cnt > mcap) ? VH_ERR_CAPACITY : VH_OK;
+  }
+
+  int32_t get_features(int32_t s, int32_t which, int32_t *out12, int32_t capo, int32_t *n) {
+    if (!n || s < 0 || s >= S || which < 0 || which > 3 || capo < 0 || (capo > 0 && !out12)) return VH_ERR_INVALID_ARG;
+    *n = 0;
+    if (!allocated) return VH_OK;
+    const int32_t set = vh_role_set(S, pair_cur, s, which);
+    int32_t cnt = 0;
+    VH_HIP(hipMemcpyAsync(&cnt, sets.count + set, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    VH_HIP(hipStreamSynchronize(stream));
+    *n = cnt;
+    const int32_t k = std::min(std::min(cnt, cap), capo);
+    if (k > 0) {
+      VH_HIP(hipMemcpyAsync(out12, sets.feat + (size_t)set * cap * 12, sizeof(int32_t) * 12 * (size_t)k,
+                            hipMemcpyDeviceToHost, stream));
+      VH_HIP(hipStreamSynchronize(stream));
+    }
+    return (cnt > capo || cnt > cap) ? VH_ERR_CAPACITY : VH_OK;
+  }
+
+  int32_t get_counts(int32_t *nf, int32_t *nm) {
+    if (!allocated) return VH_ERR_STATE;
+    if (nf) {
+      std::vector<int32_t> all(4 * (size_t)S);
+      VH_HIP(hipMemcpyAsync(all.data(), sets.count, sizeof(int32_t) * all.size(), hipMemcpyDeviceToHost, stream));
+      VH_HIP(hipStreamSynchronize(stream));
+      for (int32_t s = 0; s < S; s++)
+        for (int32_t r = 0; r < 4; r++) nf[4 * s + r] = all[vh_role_set(S, pair_cur, s, r)];
+    }
+    if (nm) {
+      VH_HIP(hipMemcpyAsync(nm, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, stream));
+      VH_HIP(hipStreamSynchronize(stream));
+    }
+    return VH_OK;
+  }
+
+  // Load caller-supplied feature records into a role's set and index it.
+  int32_t load_features(int32_t role, const int32_t *m, int32_t n) {
+    if (n < 0 || (n > 0 && !m)) return VH_ERR_INVALID_ARG;
+    if (n > cap) return VH_ERR_CAPACITY;
+    for (int32_t i = 0; i < n; i++) {
+      const int32_t *f = m + 12 * (size_t)i;
+      if (f[0] < 0 || f[0] >= dims[0] || f[1] < 0 || f[1] >= dims[1] || f[3] < 0 || f[3] > 3) return VH_ERR_INVALID_ARG;
+    }
+    const int32_t set = vh_role_set(S, pair_cur, 0, role);
+    if (n) VH_HIP(hipMemcpyAsync(sets.feat + (size_t)set * cap * 12, m, sizeof(int32_t) * 12 * (size_t)n, hipMemcpyHostToDevice, stream));
+    VH_HIP(hipMemcpyAsync(sets.count + set, &n, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    VH_HIP(hipStreamSynchronize(stream));
+    return bin_sets(set, 1, true);
+  }
+};
+
+// Matcher::rand_number (matcher.cpp:113-124): LFSR, taps {32,22,2,1}, evaluated
+// by the reference in double arithmetic; its int(floor(number/2^0)) term is an
+// out-of-range double->int conversion for number >= 2^31, which on x86-64
+// (cvttsd2si) produces INT_MIN, i.e. a 0 low bit.
+uint32_t lfsr_next(uint32_t x) {
+  uint32_t b = (x < 0x80000000u) ? (x & 1u) : 0u;
+  b ^= (x >> 10) & 1u;
+  b ^= (x >> 30) & 1u;
+  b ^= (x >> 31) & 1u;
+  return (x >> 1) + (b << 31);
+}
+
+// Matcher::bucketFeatures (matcher.cpp:140-187) without the fixed
+// buckets[126][256] capacity.
+void bucket_host(std::vector<vh_p_match> &pm, int32_t max_features, float bw, float bh) {
+  float u_max = 0, v_max = 0;
+  for (auto &m : pm) { if (m.u1c > u_max) u_max = m.u1c; if (m.v1c > v_max) v_max = m.v1c; }
+  const int32_t cols = (int32_t)floorf(u_max / bw) + 1, rows = (int32_t)floorf(v_max / bh) + 1;
+  std::vector<std::vector<vh_p_match>> buckets((size_t)cols * rows);
+  for (auto &m : pm) {
+    const int32_t u = (int32_t)floorf(m.u1c / bw), v = (int32_t)floorf(m.v1c / bh);
+    buckets[(size_t)v * cols + u].push_back(m);
+  }
+  pm.clear();
+  uint32_t rnd = 5;
+  for (auto &b : buckets) {
+    const int32_t len = (int32_t)b.size();
+    for (int32_t i = 1; i < len; i++) {  // random_shuffle, matcher.cpp:126-138
+      const int32_t j = (int32_t)(rnd % (uint32_t)(i + 1));
+      rnd = lfsr_next(rnd);
+      std::swap(b[i], b[j]);
+    }
+    for (int32_t j = 0, k = 0; j < len; j++) { pm.push_back(b[j]); if (++k >= max_features) break; }
+  }
+}
+
+int32_t check_params(const vh_params *p) {
+  if (!p) return VH_ERR_INVALID_ARG;
+  if (p->nms_n < 1 || p->nms_n > 32 || p->match_binsize < 1 || p->match_radius < 0 || p->match_disp_tolerance < 0 ||
+      p->match_radius > 16384 || p->nms_tau < 0)
+    return VH_ERR_UNSUPPORTED;
+  return VH_OK;
+}
+
+int32_t select_device(int32_t device) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { t_last_error = "no HIP device visible"; return VH_ERR_NO_DEVICE; }
+  if (device < 0 || device >= cnt) return VH_ERR_INVALID_ARG;
+  VH_HIP(hipSetDevice(device));
+  return VH_OK;
+}
+
+int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int32_t mm, Group **out) {
+  if (!out) return VH_ERR_INVALID_ARG;
+  *out = nullptr;
+  int32_t rc = check_params(p);
+  if (rc) return rc;
+  if (S < 1 || S > 65535 / 4 || mf < 0 || mm < 0) return VH_ERR_INVALID_ARG;
+  if ((rc = select_device(device))) return rc;
+  Group *gq = new Group();
+  gq->p = *p; gq->device = device; gq->S = S; gq->req_features = mf; gq->req_matches = mm;
+  if (hipStreamCreateWithFlags(&gq->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    t_last_error = "hipStreamCreateWithFlags failed";
+    gq->own_stream = nullptr; delete gq;
+    return VH_ERR_HIP;
+  }
+  gq->stream = gq->own_stream;
+  *out = gq;
+  return VH_OK;
+}
+
+#define ENTER(gq)                                   \
+  if (!(gq)) return VH_ERR_INVALID_ARG;             \
+  { hipError_t e_ = hipSetDevice((gq)->device);     \
+    if (e_ != hipSuccess) { t_last_error = hipGetErrorString(e_); return VH_ERR_HIP; } }
+
+struct Temp {  // transient one-stream group for the stateless entry points
+  Group *gq = nullptr;
+  ~Temp() { if (gq) { hipStreamSynchronize(gq->stream); delete gq; } }
+};
+
+}  // namespace
+
+// vh_group / vh_matcher are opaque aliases of Group (a matcher is a group of one stream).
+
+extern "C" {
+
+int32_t vh_abi_version(void) { return VH_ABI_VERSION; }
+
+int32_t vh_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return VH_ERR_NO_DEVICE;
+  return cnt;
+}
+
+const char *vh_error_string(int32_t code) {
+  switch (code) {
+    case VH_OK: return "ok";
+    case VH_ERR_INVALID_ARG: return "invalid argument (image dimension mismatch / null pointer)";
+    case VH_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case VH_ERR_HIP: return "HIP runtime error";
+    case VH_ERR_CAPACITY: return "capacity exceeded";
+    case VH_ERR_UNSUPPORTED: return "parameter outside the supported envelope";
+    case VH_ERR_STATE: return "call sequence error";
+    default: return "unknown error";
+  }
+}
+
+const char *vh_last_error(void) { return t_last_error.c_str(); }
+
+void vh_default_params(vh_params *p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->nms_n = 2; p->nms_tau = 50; p->match_binsize = 50; p->match_radius = 200;
+  p->match_disp_tolerance = 2; p->outlier_disp_tolerance = 5; p->outlier_flow_tolerance = 5;
+}
+
+// ---- group -----------------------------------------------------------------
+int32_t vh_group_create(const vh_params *p, int32_t device, int32_t n_streams, int32_t max_features,
+                        int32_t max_matches, vh_group **out) {
+  return group_new(p, device, n_streams, max_features, max_matches, (Group **)out);
+}
+void vh_group_destroy(vh_group *g) {
+  if (!g) return;
+  Group *gq = (Group *)g;
+  hipSetDevice(gq->device);
+  hipStreamSynchronize(gq->stream);
+  gq->prof_collect();
+  delete gq;
+}
+int32_t vh_group_streams(const vh_group *g) { return g ? ((const Group *)g)->S : VH_ERR_INVALID_ARG; }
+int32_t vh_group_push_back_device(vh_group *g, const void *dI1, const void *dI2, int64_t stride_bytes,
+                                  const int32_t dims[3], int32_t replace) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->push_device(dI1, dI2, stride_bytes, dims, replace);
+}
+int32_t vh_group_push_back(vh_group *g, const uint8_t *I1, const uint8_t *I2, int64_t stride_bytes,
+                           const int32_t dims[3], int32_t replace) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->push_host(I1, I2, stride_bytes, dims, replace);
+}
+int32_t vh_group_match_features(vh_group *g, int32_t method) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->match(method);
+}
+int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32_t cap, int32_t *n) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->get_matches(stream, out, cap, n);
+}
+int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_t *out12, int32_t cap, int32_t *n) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->get_features(stream, which, out12, cap, n);
+}
+int32_t vh_group_get_counts(vh_group *g, int32_t *n_features, int32_t *n_matches) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->get_counts(n_features, n_matches);
+}
+int32_t vh_group_synchronize(vh_group *g) {
+  Group *gq = (Group *)g; ENTER(gq);
+  VH_HIP(hipStreamSynchronize(gq->stream));
+  return VH_OK;
+}
+int32_t vh_group_set_stream(vh_group *g, void *hip_stream) {
+  Group *gq = (Group *)g; ENTER(gq);
+  VH_HIP(hipStreamSynchronize(gq->stream));
+  gq->stream = hip_stream ? (hipStream_t)hip_stream : gq->own_stream;
+  return VH_OK;
+}
+int32_t vh_group_profile_enable(vh_group *g, int32_t on) {
+  Group *gq = (Group *)g; ENTER(gq);
+  gq->prof = on != 0;
+  return VH_OK;
+}
+int32_t vh_group_profile_read(vh_group *g, const char *name, double *ms, int64_t *launches) {
+  Group *gq = (Group *)g; ENTER(gq);
+  if (!name) return VH_ERR_INVALID_ARG;
+  gq->prof_collect();
+  auto it = gq->prof_entries.find(name);
+  if (ms) *ms = it == gq->prof_entries.end() ? 0.0 : it->second.ms;
+  if (launches) *launches = it == gq->prof_entries.end() ? 0 : it->second.launches;
+  return VH_OK;
+}
+int32_t vh_group_profile_reset(vh_group *g) {
+  Group *gq = (Group *)g; ENTER(gq);
+  gq->prof_collect();
+  gq->prof_entries.clear();
+  return VH_OK;
+}
+
+// ---- one stream ------------------------------------------------------------
+int32_t vh_create_ex(const vh_params *p, int32_t device, int32_t max_features, int32_t max_matches,
+                     vh_matcher **out) {
+  return group_new(p, device, 1, max_features, max_matches, (Group **)out);
+}
+int32_t vh_create(const vh_params *p, int32_t device, vh_matcher **out) { return vh_create_ex(p, device, 0, 0, out); }
+void vh_destroy(vh_matcher *m) { vh_group_destroy((vh_group *)m); }
+int32_t vh_set_intrinsics(vh_matcher *m, double f, double cu, double cv, double base) {
+  if (!m) return VH_ERR_INVALID_ARG;
+  Group *gq = (Group *)m;
+  gq->p.f = f; gq->p.cu = cu; gq->p.cv = cv; gq->p.base = base;
+  return VH_OK;
+}
+int32_t vh_push_back(vh_matcher *m, const uint8_t *I1, const uint8_t *I2, const int32_t dims[3], int32_t replace) {
+  Group *gq = (Group *)m; ENTER(gq);
+  return gq->push_host(I1, I2, 0, dims, replace);
+}
+int32_t vh_push_back_device(vh_matcher *m, const void *dI1, const void *dI2, const int32_t dims[3], int32_t replace) {
+  Group *gq = (Group *)m; ENTER(gq);
+  return gq->push_device(dI1, dI2, 0, dims, replace);
+}
+int32_t vh_match_features(vh_matcher *m, int32_t method, const double *Tr_delta16) {
+  (void)Tr_delta16;  // accepted and ignored, as Matcher::matchFeatures does (matcher.cpp:93-111)
+  Group *gq = (Group *)m; ENTER(gq);
+  return gq->match(method);
+}
+int32_t vh_bucket_features(vh_matcher *m, int32_t max_features, float bucket_width, float bucket_height) {
+  Group *gq = (Group *)m; ENTER(gq);
+  if (max_features < 1 || !(bucket_width > 0) || !(bucket_height > 0)) return VH_ERR_INVALID_ARG;
+  int32_t n = 0;
+  int32_t rc = gq->get_matches(0, nullptr, 0, &n);
+  if (rc != VH_OK && rc != VH_ERR_CAPACITY) return rc;
+  if (n > gq->mcap) return VH_ERR_CAPACITY;
+  std::vector<vh_p_match> pm((size_t)n);
+  if (n && (rc = gq->get_matches(0, pm.data(), n, &n))) return rc;
+  bucket_host(pm, max_features, bucket_width, bucket_height);
+  gq->host_matches.swap(pm);
+  gq->bucketed = true;
+  return VH_OK;
+}
+int32_t vh_get_matches(vh_matcher *m, vh_p_match *out, int32_t cap, int32_t *n) {
+  Group *gq = (Group *)m; ENTER(gq);
+  return gq->get_matches(0, out, cap, n);
+}
+int32_t vh_get_features(vh_matcher *m, int32_t which, int32_t *out12, int32_t cap, int32_t *n) {
+  Group *gq = (Group *)m; ENTER(gq);
+  return gq->get_features(0, which, out12, cap, n);
+}
+int32_t vh_synchronize(vh_matcher *m) { return vh_group_synchronize((vh_group *)m); }
+int32_t vh_set_stream(vh_matcher *m, void *hip_stream) { return vh_group_set_stream((vh_group *)m, hip_stream); }
+
+// ---- stateless primitives ----------------------------------------------------
+int32_t vh_filters(int32_t device, const uint8_t *I, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
+                   int16_t *f1, int16_t *f2) {
+  if (!I || bpl < 5 || H < 5) return VH_ERR_INVALID_ARG;
+  int32_t rc = select_device(device);
+  if (rc) return rc;
+  const size_t n = (size_t)bpl * H;
+  uint8_t *d = nullptr;
+  VH_HIP(hipMalloc((void **)&d, n * 7));
+  uint8_t *dI = d, *ddu = d + n, *ddv = d + 2 * n;
+  int16_t *df1 = (int16_t *)(d + 3 * n), *df2 = (int16_t *)(d + 5 * n);
+  hipError_t e = hipMemcpy(dI, I, n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    vh_launch_planes(dI, bpl, H, ddu, ddv, df1, df2, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess && du) e = hipMemcpy(du, ddu, n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && dv) e = hipMemcpy(dv, ddv, n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && f1) e = hipMemcpy(f1, df1, 2 * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && f2) e = hipMemcpy(f2, df2, 2 * n, hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) { t_last_error = hipGetErrorString(e); return VH_ERR_HIP; }
+  return VH_OK;
+}
+
+int32_t vh_compute_features(const vh_params *p, int32_t device, const uint8_t *I, const int32_t dims[3],
+                            int32_t *max1, int32_t cap1, int32_t *num1, int32_t *max2, int32_t cap2,
+                            int32_t *num2, uint8_t *du, uint8_t *dv) {
+  if (!p || !I || !dims) return VH_ERR_INVALID_ARG;
+  if (num1) *num1 = 0;
+  if (num2) *num2 = 0;
+  int32_t rc, overflow = VH_OK;
+  {  // dense set (matcher.cpp:634-635)
+    Temp t;
+    if ((rc = group_new(p, device, 1, 0, 0, &t.gq))) return rc;
+    if ((rc = t.gq->push_host(I, nullptr, 0, dims, 0))) return rc;
+    int32_t n = 0;
+    rc = t.gq->get_features(0, VH_SET_1C, max2, max2 ? cap2 : 0, &n);
+    if (num2) *num2 = n;
+    if (rc == VH_ERR_CAPACITY) overflow = rc; else if (rc) return rc;
+    if (du || dv) {  // I_du / I_dv at matching resolution (matcher.cpp:596-600, :606-612)
+      const VhGeom &g = t.gq->g;
+      const size_t np = (size_t)g.bplm * g.Hm;
+      uint8_t *d = nullptr;
+      VH_HIP(hipMalloc((void **)&d, 2 * np));
+      const uint8_t *src = p->half_resolution ? t.gq->d_half : t.gq->d_stage[0];
+      vh_launch_planes(src, g.bplm, g.Hm, d, d + np, nullptr, nullptr, t.gq->stream);
+      hipError_t e = hipStreamSynchronize(t.gq->stream);
+      if (e == hipSuccess && du) e = hipMemcpy(du, d, np, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && dv) e = hipMemcpy(dv, d + np, np, hipMemcpyDeviceToHost);
+      hipFree(d);
+      if (e != hipSuccess) { t_last_error = hipGetErrorString(e); return VH_ERR_HIP; }
+    }
+  }
+  if (p->multi_stage) {  // sparse set (matcher.cpp:621-628)
+    vh_params ps = *p;
+    int32_t ns = p->nms_n * 4;
+    if (ns > 10) ns = std::max(p->nms_n, 10);
+    ps.nms_n = ns;
+    Temp t;
+    if ((rc = group_new(&ps, device, 1, 0, 0, &t.gq))) return rc;
+    if ((rc = t.gq->push_host(I, nullptr, 0, dims, 0))) return rc;
+    int32_t n = 0;
+    rc = t.gq->get_features(0, VH_SET_1C, max1, max1 ? cap1 : 0, &n);
+    if (num1) *num1 = n;
+    if (rc == VH_ERR_CAPACITY) overflow = rc; else if (rc) return rc;
+  }
+  return overflow;
+}
+
+int32_t vh_create_index(const vh_params *p, int32_t device, const int32_t dims[3], const int32_t *m,
+                        int32_t n, int32_t *bin_start, int32_t *list) {
+  if (!p || !dims || !bin_start || (n > 0 && !list)) return VH_ERR_INVALID_ARG;
+  Temp t;
+  int32_t rc;
+  if ((rc = group_new(p, device, 1, std::max(n, 64), 1, &t.gq))) return rc;
+  const int32_t d[3] = {dims[0], dims[1], std::max(dims[2], dims[0])};
+  if ((rc = t.gq->ensure(d))) return rc;
+  if ((rc = t.gq->load_features(VH_SET_1C, m, n))) return rc;
+  Group *gq = t.gq;
+  int32_t *d_bs = nullptr, *d_list = nullptr;
+  if ((rc = gq->dmalloc(&d_bs, (size_t)gq->sets.nbins + 1, false))) return rc;
+  if ((rc = gq->dmalloc(&d_list, (size_t)std::max(n, 1), false))) return rc;
+  vh_launch_ref_index(gq->sets, vh_role_set(1, gq->pair_cur, 0, VH_SET_1C), d_bs, d_list, gq->stream);
+  VH_HIP(hipMemcpyAsync(bin_start, d_bs, sizeof(int32_t) * ((size_t)gq->sets.nbins + 1), hipMemcpyDeviceToHost, gq->stream));
+  if (n) VH_HIP(hipMemcpyAsync(list, d_list, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, gq->stream));
+  VH_HIP(hipStreamSynchronize(gq->stream));
+  return VH_OK;
+}
+
+int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3], const int32_t *m1, int32_t n1,
+                     const int32_t *m2, int32_t n2, int32_t flow, int32_t *best) {
+  if (!p || !dims || (n1 > 0 && !best)) return VH_ERR_INVALID_ARG;
+  Temp t;
+  int32_t rc;
+  if ((rc = group_new(p, device, 1, std::max(std::max(n1, n2), 64), 1, &t.gq))) return rc;
+  const int32_t d[3] = {dims[0], dims[1], std::max(dims[2], dims[0])};
+  Group *gq = t.gq;
+  if ((rc = gq->ensure(d))) return rc;
+  if ((rc = gq->load_features(VH_SET_1C, m1, n1))) return rc;
+  if ((rc = gq->load_features(VH_SET_1P, m2, n2))) return rc;
+  VhMatchArgs a = gq->match_args(VH_METHOD_FLOW);
+  a.npass = 1; a.pass[0] = {VH_SET_1C, VH_SET_1P, flow ? 1 : 0};
+  vh_launch_match(gq->sets, a, gq->d_best, gq->stream);
+  VH_HIP(hipGetLastError());
+  if (n1) VH_HIP(hipMemcpyAsync(best, gq->d_best, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, gq->stream));
+  VH_HIP(hipStreamSynchronize(gq->stream));
+  return VH_OK;
+}
+
+int32_t vh_match(const vh_params *p, int32_t device, const int32_t dims[3], int32_t method, const int32_t *m1p,
+                 int32_t n1p, const int32_t *m2p, int32_t n2p, const int32_t *m1c, int32_t n1c,
+                 const int32_t *m2c, int32_t n2c, vh_p_match *out, int32_t cap, int32_t *n) {
+  if (!p || !dims || !n) return VH_ERR_INVALID_ARG;
+  if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
+  Temp t;
+  int32_t rc;
+  const int32_t nmax = std::max(std::max(n1p, n2p), std::max(n1c, n2c));
+  if ((rc = group_new(p, device, 1, std::max(nmax, 64), std::max(nmax, 64), &t.gq))) return rc;
+  const int32_t d[3] = {dims[0], dims[1], std::max(dims[2], dims[0])};
+  Group *gq = t.gq;
+  if ((rc = gq->ensure(d))) return rc;
+  if ((rc = gq->load_features(VH_SET_1P, m1p, n1p))) return rc;
+  if ((rc = gq->load_features(VH_SET_2P, m2p, n2p))) return rc;
+  if ((rc = gq->load_features(VH_SET_1C, m1c, n1c))) return rc;
+  if ((rc = gq->load_features(VH_SET_2C, m2c, n2c))) return rc;
+  if ((rc = gq->match(method))) return rc;
+  return gq->get_matches(0, out, cap, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// kernels_bin.hip -- position/class bin index of a feature set on gfx950.
+//
+// Replaces Matcher::createIndexVector (reference src/matcher.cpp:194-214).
+// The reference keeps one std::vector<int32_t> per bin, filled in ascending
+// feature order.  Here a feature set is *reordered* into bin order once
+// (counting sort: histogram -> scan -> fill -> per-bin order restore) and kept
+// as structure-of-arrays (s_uv, s_idx, s_desc), so that the matcher streams
+// candidates of a bin range as one contiguous, coalesced segment.
+//
+// Bin numbering here is u-bin major, (c*ubn+ub)*vbn+vb, so that the order
+// "u_bin outer, v_bin inner, list position innermost" in which
+// Matcher::findMatch visits candidates (src/matcher.cpp:243-246) is simply
+// ascending position -- the first-minimum tie-break becomes "lowest position".
+#include "vh_dev.h"
+
+namespace {
+
+__device__ __forceinline__ int32_t bin_coord(int32_t x, int32_t binsize, int32_t nb) {
+  // min((int)floor((float)x/(float)binsize), nb-1)   (matcher.cpp:208-209).
+  // For 0 <= x < 2^24 the float quotient floors to the integer quotient.
+  return min(x / binsize, nb - 1);
+}
+
+__device__ __forceinline__ int32_t feature_bin(const int32_t *__restrict__ f, const VhSets &s) {
+  const int32_t u = f[0], v = f[1], c = f[3];
+  return (c * s.ubn + bin_coord(u, s.binsize, s.ubn)) * s.vbn + bin_coord(v, s.binsize, s.vbn);
+}
+
+__global__ void bin_hist_kernel(VhSets s, int32_t set0) {
+  const int32_t set = set0 + blockIdx.y;
+  const int32_t n = min(s.count[set], s.cap);
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t b = feature_bin(s.feat + ((int64_t)set * s.cap + i) * 12, s);
+  atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
+}
+
+// One workgroup per set: exclusive scan of the histogram into bin_start, and
+// the list of query tiles (<= 64 consecutive bin-ordered features of one
+// (class, u-bin) column) the match kernel works through.
+__global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) {
+  __shared__ int32_t sPart[1024];
+  __shared__ int32_t sCarry;
+  const int32_t set = set0 + blockIdx.x, tid = threadIdx.x;
+  const int32_t *__restrict__ hist = s.hist + (int64_t)set * s.nbins;
+  int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
+  if (tid == 0) sCarry = 0;
+  __syncthreads();
+  for (int32_t b0 = 0; b0 < s.nbins; b0 += 1024) {
+    const int32_t b = b0 + tid;
+    const int32_t v = (b < s.nbins) ? hist[b] : 0;
+    sPart[tid] = v;
+    __syncthreads();
+    for (int32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+      const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
+      __syncthreads();
+      sPart[tid] += t;
+      __syncthreads();
+    }
+    const int32_t incl = sPart[tid], carry = sCarry;
+    if (b < s.nbins) bs[b] = carry + incl - v;
+    __syncthreads();
+    if (tid == 1023) sCarry = carry + incl;
+    __syncthreads();
+  }
+  if (tid == 0) bs[s.nbins] = sCarry;
+  __syncthreads();
+
+  // query tiles: column (c,ub) owns positions [bs[col*vbn], bs[(col+1)*vbn])
+  const int32_t ncol = 4 * s.ubn;
+  int4 *__restrict__ tiles = s.tiles + (int64_t)set * s.max_tiles;
+  if (tid == 0) sCarry = 0;
+  __syncthreads();
+  for (int32_t c0 = 0; c0 < ncol; c0 += 1024) {
+    const int32_t col = c0 + tid;
+    int32_t q0 = 0, q1 = 0;
+    if (col < ncol) { q0 = bs[col * s.vbn]; q1 = bs[(col + 1) * s.vbn]; }
+    const int32_t nt = (q1 - q0 + 63) >> 6;
+    sPart[tid] = nt;
+    __syncthreads();
+    for (int32_t d = 1; d < 1024; d <<= 1) {
+      const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
+      __syncthreads();
+      sPart[tid] += t;
+      __syncthreads();
+    }
+    const int32_t incl = sPart[tid], carry = sCarry;
+    int32_t t0 = carry + incl - nt;
+    for (int32_t k = 0; k < nt; k++, t0++)
+      if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + 64 * k, min(q1, q0 + 64 * k + 64), col / s.ubn, col % s.ubn);
+    __syncthreads();
+    if (tid == 1023) sCarry = carry + incl;
+    __syncthreads();
+  }
+  if (tid == 0) s.tile_cnt[set] = min(sCarry, s.max_tiles);
+}
+
+__global__ void bin_fill_kernel(VhSets s, int32_t set0) {
+  const int32_t set = set0 + blockIdx.y;
+  const int32_t n = min(s.count[set], s.cap);
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t b = feature_bin(s.feat + ((int64_t)set * s.cap + i) * 12, s);
+  const int32_t slot = s.bin_start[(int64_t)set * (s.nbins + 1) + b] + atomicAdd(&s.cursor[(int64_t)set * s.nbins + b], 1);
+  s.tmp_idx[(int64_t)set * s.cap + slot] = i;
+}
+
+// One wave per bin: the atomic fill left the bin's members in arbitrary order;
+// rank-sort them back to ascending feature index (the reference's push_back
+// order) and gather the bin-ordered structure-of-arrays.
+__global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0) {
+  const int32_t set = set0 + blockIdx.y;
+  const int32_t bin = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (bin >= s.nbins) return;
+  const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
+  const int32_t p0 = bs[bin], p1 = bs[bin + 1], L = p1 - p0;
+  if (L <= 0) return;
+  const int32_t *__restrict__ tmp = s.tmp_idx + (int64_t)set * s.cap;
+  const int32_t *__restrict__ feat = s.feat + (int64_t)set * s.cap * 12;
+  int32_t *__restrict__ sidx = s.s_idx + (int64_t)set * s.cap;
+  uint32_t *__restrict__ suv = s.s_uv + (int64_t)set * s.cap;
+  uint4 *__restrict__ sdesc = (uint4 *)(s.s_desc + (int64_t)set * s.cap * 8);
+  for (int32_t e0 = 0; e0 < L; e0 += 64) {
+    const int32_t e = e0 + lane;
+    const int32_t mine = (e < L) ? tmp[p0 + e] : 0x7FFFFFFF;
+    int32_t rank = 0;
+    for (int32_t j0 = 0; j0 < L; j0 += 64) {
+      const int32_t other = (j0 + lane < L) ? tmp[p0 + j0 + lane] : 0x7FFFFFFF;
+      const int32_t m = min(64, L - j0);
+      for (int32_t j = 0; j < m; j++) rank += (__shfl(other, j) < mine) ? 1 : 0;
+    }
+    if (e < L) {
+      const int32_t p = p0 + rank;
+      const int32_t *f = feat + (int64_t)mine * 12;
+      const uint4 h = *(const uint4 *)f, d0 = *(const uint4 *)(f + 4), d1 = *(const uint4 *)(f + 8);
+      sidx[p] = mine;
+      suv[p] = (uint32_t)h.x | ((uint32_t)h.y << 16);
+      sdesc[2 * (int64_t)p] = d0;
+      sdesc[2 * (int64_t)p + 1] = d1;
+    }
+  }
+}
+
+// CSR in the reference's own bin numbering (c*vbn+vb)*ubn+ub, for
+// vh_create_index (parity check of Matcher::createIndexVector).
+__global__ void ref_index_kernel(VhSets s, int32_t set, int32_t *__restrict__ bs_ref,
+                                 int32_t *__restrict__ list_ref) {
+  // single workgroup: sequential over reference bins, parallel inside a bin
+  __shared__ int32_t sPos;
+  const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
+  const int32_t *__restrict__ sidx = s.s_idx + (int64_t)set * s.cap;
+  if (threadIdx.x == 0) sPos = 0;
+  __syncthreads();
+  for (int32_t rb = 0; rb < s.nbins; rb++) {
+    const int32_t ub = rb % s.ubn, vb = (rb / s.ubn) % s.vbn, c = rb / (s.ubn * s.vbn);
+    const int32_t ib = (c * s.ubn + ub) * s.vbn + vb;
+    const int32_t p0 = bs[ib], L = bs[ib + 1] - p0, pos = sPos;
+    if (threadIdx.x == 0) bs_ref[rb] = pos;
+    for (int32_t e = threadIdx.x; e < L; e += blockDim.x) list_ref[pos + e] = sidx[p0 + e];
+    __syncthreads();
+    if (threadIdx.x == 0) sPos = pos + L;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bs_ref[s.nbins] = sPos;
+}
+
+}  // namespace
+
+void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
+  dim3 grid((s.cap + 255) / 256, nsets);
+  hipLaunchKernelGGL(bin_hist_kernel, grid, dim3(256), 0, st, s, set0);
+}
+void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(nsets), dim3(1024), 0, st, s, set0);
+}
+void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
+  dim3 grid((s.cap + 255) / 256, nsets);
+  hipLaunchKernelGGL(bin_fill_kernel, grid, dim3(256), 0, st, s, set0);
+}
+void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
+  dim3 grid((s.nbins + 3) / 4, nsets);
+  hipLaunchKernelGGL(bin_sort_kernel, grid, dim3(256), 0, st, s, set0);
+}
+void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, int32_t *list_ref,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(ref_index_kernel, dim3(1), dim3(256), 0, st, s, set, bin_start_ref, list_ref);
+}

@@ -1,0 +1,351 @@
+// kernels_detect.hip -- feature detection on gfx950.
+//
+// Replaces, for every image of every stream in one launch:
+//   filter::blob5x5 / checkerboard5x5     (reference src/filter.cpp:445-467, :433-438)
+//   Matcher::nonMaximumSuppression        (reference src/matcher.cpp:366-468)
+//   filter::sobel5x5 + computeDescriptor  (reference src/filter.cpp:418-426,
+//                                          src/matcher.cpp:470-514)
+//   the packing loop of computeFeatures   (reference src/matcher.cpp:663-671)
+//
+// Design (HBM-bound integer work, no MFMA):
+//   detect_nms    one workgroup per tile of NMS blocks: the image tile (+halo)
+//                 is staged in LDS once, the blob and checkerboard responses
+//                 are produced into LDS by a separable sliding-window pass and
+//                 never touch HBM, NMS runs on the LDS tile (one lane per NMS
+//                 block) and leaves 8 bytes per block (4 x u16 position codes).
+//   emit_features ordered compaction of those codes (reference output order:
+//                 block row-major, class ascending), then the 32-byte
+//                 descriptor of each survivor is computed straight from the
+//                 image (16 lanes per feature, one sample point each): the
+//                 Sobel planes the reference materialises are never written.
+#include "vh_dev.h"
+
+namespace {
+
+// ---------------------------------------------------------------- half-res
+// Matcher::createHalfResolutionImage (reference src/matcher.cpp:572-583);
+// padding columns [Wm,bplm) are written as zero.
+__global__ void half_res_kernel(VhImages src, uint8_t *__restrict__ dst, VhGeom g) {
+  const int32_t id = blockIdx.z;
+  const uint8_t *__restrict__ I = vh_image_ptr(src, id);
+  uint8_t *__restrict__ O = dst + (int64_t)id * g.bplm * g.Hm;
+  const int32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t v = blockIdx.y;
+  if (u >= g.bplm) return;
+  uint32_t val = 0;
+  if (u < g.Wm) {
+    const int64_t r0 = (int64_t)(2 * v) * g.bpl + 2 * u, r1 = r0 + g.bpl;
+    val = ((uint32_t)I[r0] + I[r0 + 1] + I[r1] + I[r1 + 1]) >> 2;
+  }
+  O[(int64_t)v * g.bplm + u] = (uint8_t)val;
+}
+
+// --------------------------------------------------------------- detect_nms
+// LDS: sI[IH][IWp] u8 | sF1[FH][FWp] i16 | sF2[FH][FWp] i16
+//
+// Tile geometry (n = nms_n): the tile owns tbx x tby NMS blocks whose first
+// pixel is (n+7 + bx0*(n+1), n+7 + by0*(n+1)); responses are needed n pixels
+// around the blocks and the image 2 pixels around the responses.
+__global__ void __launch_bounds__(256)
+detect_nms_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__restrict__ chunk_count) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t *sI = smem;
+  int16_t *sF1 = (int16_t *)(smem + (size_t)g.IH * g.IWp);
+  int16_t *sF2 = sF1 + (size_t)g.FH * g.FWp;
+
+  const int32_t id = blockIdx.z;
+  const uint8_t *__restrict__ I = vh_image_ptr(im, id);
+  const int32_t n = g.n, n1 = n + 1;
+  const int32_t bx0 = blockIdx.x * g.tbx, by0 = blockIdx.y * g.tby;
+  const int32_t fx0 = VH_MARGIN + bx0 * n1, fy0 = VH_MARGIN + by0 * n1;  // response tile origin
+  const int32_t ix0 = fx0 - 2, iy0 = fy0 - 2;                            // image tile origin
+  const int32_t tid = threadIdx.x;
+
+  // 1. stage the image tile (rows/cols outside the image read as 0; they only
+  //    feed responses that NMS never looks at)
+  for (int32_t k = tid; k < g.IH * g.IWp; k += 256) {
+    const int32_t r = k / g.IWp, c = k - r * g.IWp;
+    const int32_t gx = ix0 + c, gy = iy0 + r;
+    uint8_t v = 0;
+    if (c < g.IW && gx < g.bplm && gy < g.Hm) v = I[(int64_t)gy * g.bplm + gx];
+    sI[k] = v;
+  }
+  __syncthreads();
+
+  // 2. blob (f1) and checkerboard (f2) responses, separable sliding window
+  //    down each column.  Row sums of image-tile row y around centre column cx+2:
+  //      h5 = a+b+c+d+e, h3 = b+c+d, hc = a+b-d-e
+  //    f2(y) = hc(y-2)+hc(y-1)-hc(y+1)-hc(y+2)              (filter.cpp:339-347,:365-367)
+  //    f1(y) = -sum5(h5) + 2*sum3(h3) + 7*c(y)               (filter.cpp:461-463)
+  {
+    const int32_t nseg = max(1, 256 / g.FW);
+    const int32_t rows_per = (g.FH + nseg - 1) / nseg;
+    for (int32_t task = tid; task < g.FW * nseg; task += 256) {
+      const int32_t seg = task / g.FW, cx = task - seg * g.FW;
+      const int32_t r0 = seg * rows_per, r1 = min(g.FH, r0 + rows_per);
+      if (r0 >= r1) continue;
+      int32_t h5[5], h3[5], hc[5], cc[5];
+      // response row fr uses image-tile rows fr .. fr+4 (centre fr+2)
+#pragma unroll
+      for (int32_t k = 0; k < 4; k++) {
+        const uint8_t *p = sI + (size_t)(r0 + k) * g.IWp + cx;
+        const int32_t a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+        h5[k + 1] = a + b + c + d + e; h3[k + 1] = b + c + d; hc[k + 1] = a + b - d - e; cc[k + 1] = c;
+      }
+      for (int32_t fr = r0; fr < r1; fr++) {
+#pragma unroll
+        for (int32_t k = 0; k < 4; k++) { h5[k] = h5[k + 1]; h3[k] = h3[k + 1]; hc[k] = hc[k + 1]; cc[k] = cc[k + 1]; }
+        const uint8_t *p = sI + (size_t)(fr + 4) * g.IWp + cx;
+        const int32_t a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+        h5[4] = a + b + c + d + e; h3[4] = b + c + d; hc[4] = a + b - d - e; cc[4] = c;
+        const int32_t f2 = hc[0] + hc[1] - hc[3] - hc[4];
+        const int32_t f1 = -(h5[0] + h5[1] + h5[2] + h5[3] + h5[4]) + 2 * (h3[1] + h3[2] + h3[3]) + 7 * cc[2];
+        sF1[(size_t)fr * g.FWp + cx] = (int16_t)f1;
+        sF2[(size_t)fr * g.FWp + cx] = (int16_t)f2;
+      }
+    }
+  }
+  __syncthreads();
+
+  // 3. NMS, one lane per block (Neubeck/Van Gool alg. 4, matcher.cpp:381-466)
+  if (tid >= g.tbx * g.tby) return;
+  const int32_t lby = tid / g.tbx, lbx = tid - lby * g.tbx;
+  const int32_t bx = bx0 + lbx, by = by0 + lby;
+  if (bx >= g.nbx || by >= g.nby) return;
+  const int32_t fx = n + lbx * n1, fy = n + lby * n1;  // block origin in response-tile coords
+  // clip limits W-1-margin / H-1-margin in response-tile coords (matcher.cpp:420-421)
+  const int32_t xlim = (g.Wm - 1 - VH_MARGIN) - fx0, ylim = (g.Hm - 1 - VH_MARGIN) - fy0;
+
+  int32_t ex[4], ey[4], ev[4];
+  ex[0] = ex[1] = ex[2] = ex[3] = fx;
+  ey[0] = ey[1] = ey[2] = ey[3] = fy;
+  ev[0] = ev[1] = sF1[(size_t)fy * g.FWp + fx];
+  ev[2] = ev[3] = sF2[(size_t)fy * g.FWp + fx];
+  for (int32_t j2 = fy; j2 <= fy + n; j2++) {
+    for (int32_t i2 = fx; i2 <= fx + n; i2++) {
+      int32_t cur = sF1[(size_t)j2 * g.FWp + i2];
+      if (cur < ev[0]) { ex[0] = i2; ey[0] = j2; ev[0] = cur; }       // first extremum in scan order wins
+      else if (cur > ev[1]) { ex[1] = i2; ey[1] = j2; ev[1] = cur; }  // (matcher.cpp:397-405)
+      cur = sF2[(size_t)j2 * g.FWp + i2];
+      if (cur < ev[2]) { ex[2] = i2; ey[2] = j2; ev[2] = cur; }
+      else if (cur > ev[3]) { ex[3] = i2; ey[3] = j2; ev[3] = cur; }
+    }
+  }
+  uint64_t code = 0;
+  int32_t cnt = 0;
+#pragma unroll
+  for (int32_t c = 0; c < 4; c++) {
+    const int16_t *F = (c < 2) ? sF1 : sF2;
+    const bool is_min = (c & 1) == 0;
+    const int32_t val = ev[c];
+    bool ok = is_min ? (val <= -g.tau) : (val >= g.tau);  // threshold (matcher.cpp:427,439,451,463)
+    if (ok) {
+      const int32_t jhi = min(ey[c] + n, ylim), ihi = min(ex[c] + n, xlim);
+      for (int32_t j2 = ey[c] - n; j2 <= jhi && ok; j2++) {
+        for (int32_t i2 = ex[c] - n; i2 <= ihi; i2++) {
+          const int32_t cur = F[(size_t)j2 * g.FWp + i2];
+          const bool outside = (i2 < fx) | (i2 > fx + n) | (j2 < fy) | (j2 > fy + n);
+          if (outside && (is_min ? (cur < val) : (cur > val))) { ok = false; break; }
+        }
+      }
+    }
+    const uint32_t pc = ok ? (uint32_t)((ey[c] - fy) * n1 + (ex[c] - fx)) : VH_NO_CODE;
+    code |= (uint64_t)pc << (16 * c);
+    cnt += ok ? 1 : 0;
+  }
+  const int32_t blk = by * g.nbx + bx;
+  rec[(int64_t)id * g.nblocks + blk] = code;
+  if (cnt) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + blk / VH_CHUNK], cnt);
+}
+
+// ------------------------------------------------------------- emit_features
+// One workgroup per VH_CHUNK consecutive NMS blocks (row-major == reference
+// output order).  Phase A: ordered compaction of the chunk's survivors into an
+// LDS list; phase B: 16 lanes per survivor compute its descriptor from the
+// image and the 12-word record is stored with 48-byte-contiguous writes.
+__device__ __forceinline__ int32_t wave_incl_scan(int32_t v) {
+#pragma unroll
+  for (int32_t d = 1; d < 64; d <<= 1) {
+    const int32_t t = __shfl_up(v, d);
+    if ((int32_t)(threadIdx.x & 63) >= d) v += t;
+  }
+  return v;
+}
+
+// sample-point offsets of the 16 (du,dv) pairs, byte order of matcher.cpp:482-513
+__constant__ int8_t c_desc_dx[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
+__constant__ int8_t c_desc_dy[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
+
+__global__ void __launch_bounds__(256)
+emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
+                     const int32_t *__restrict__ chunk_count, int32_t *__restrict__ feat,
+                     int32_t *__restrict__ count, int32_t cap) {
+  __shared__ uint32_t sList[4 * VH_CHUNK];  // u | v<<14 | c<<28 (matching-resolution coords)
+  __shared__ int32_t sWave[4];
+  __shared__ int32_t sBase;
+
+  const int32_t id = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const uint8_t *__restrict__ I = vh_image_ptr(im, id);
+  const int32_t set = vh_image_set(im, id);
+  const int32_t n1 = g.n + 1;
+
+  // features emitted by earlier chunks of this image
+  int32_t part = 0;
+  for (int32_t k = tid; k < chunk; k += 256) part += chunk_count[(int64_t)id * g.nchunks + k];
+#pragma unroll
+  for (int32_t d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  if ((tid & 63) == 0) sWave[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) sBase = sWave[0] + sWave[1] + sWave[2] + sWave[3];
+  __syncthreads();
+  const int32_t base = sBase;
+  __syncthreads();
+
+  // phase A: each lane owns 4 consecutive blocks
+  uint64_t codes[4];
+  int32_t mine = 0;
+#pragma unroll
+  for (int32_t k = 0; k < 4; k++) {
+    const int32_t blk = chunk * VH_CHUNK + tid * 4 + k;
+    uint64_t c = ~0ull;
+    if (blk < g.nblocks) c = rec[(int64_t)id * g.nblocks + blk];
+    codes[k] = c;
+#pragma unroll
+    for (int32_t q = 0; q < 4; q++) mine += (((c >> (16 * q)) & 0xFFFF) != VH_NO_CODE) ? 1 : 0;
+  }
+  const int32_t incl = wave_incl_scan(mine);
+  if ((tid & 63) == 63) sWave[tid >> 6] = incl;
+  __syncthreads();
+  int32_t woff = 0;
+  for (int32_t w = 0; w < (tid >> 6); w++) woff += sWave[w];
+  const int32_t total = sWave[0] + sWave[1] + sWave[2] + sWave[3];
+  int32_t pos = woff + incl - mine;
+#pragma unroll
+  for (int32_t k = 0; k < 4; k++) {
+    const int32_t blk = chunk * VH_CHUNK + tid * 4 + k;
+    const int32_t by = blk / g.nbx, bx = blk - by * g.nbx;
+    const int32_t px = g.n + VH_MARGIN + bx * n1, py = g.n + VH_MARGIN + by * n1;
+#pragma unroll
+    for (int32_t q = 0; q < 4; q++) {
+      const uint32_t pc = (uint32_t)(codes[k] >> (16 * q)) & 0xFFFF;
+      if (pc != VH_NO_CODE) {
+        const int32_t dj = pc / n1, di = pc - dj * n1;
+        sList[pos++] = (uint32_t)(px + di) | ((uint32_t)(py + dj) << 14) | ((uint32_t)q << 28);
+      }
+    }
+  }
+  __syncthreads();
+  if (chunk == g.nchunks - 1 && tid == 0) count[set] = base + total;
+
+  // phase B: 16 lanes per feature, lane k = sample point k
+  const int32_t grp = tid >> 4, k = tid & 15;
+  const int32_t dx = c_desc_dx[k], dy = c_desc_dy[k];
+  int32_t *__restrict__ out = feat + (int64_t)set * cap * 12;
+  for (int32_t f0 = 0; f0 < total; f0 += 16) {
+    const int32_t f = f0 + grp;
+    const bool live = f < total;
+    const uint32_t e = sList[live ? f : 0];
+    const int32_t u = e & 0x3FFF, v = (e >> 14) & 0x3FFF, c = e >> 28;
+    // 5x5 Sobel pair at (u+dx, v+dy): du = smooth_y (x) deriv_x, dv = deriv_y (x) smooth_x
+    // (filter.cpp:288-318 column pass, :132-171 / :79-127 row passes)
+    const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (u + dx - 2);
+    int32_t a_du = 0, a_dv = 0;
+    if (live) {
+#pragma unroll
+      for (int32_t r = 0; r < 5; r++) {
+        const int32_t a = p[0], b = p[1], cc = p[2], d = p[3], ee = p[4];
+        const int32_t rowD = a + 2 * b - 2 * d - ee;
+        const int32_t rowS = a + 4 * b + 6 * cc + 4 * d + ee;
+        const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
+        const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
+        a_du += sw * rowD;
+        a_dv += dw * rowS;
+        p += g.bplm;
+      }
+    }
+    // arithmetic >>7, +128, unsigned saturation (filter.cpp:114-115,124 / :159-160,168)
+    const uint32_t du = (uint32_t)min(255, max(0, (a_du >> 7) + 128));
+    const uint32_t dv = (uint32_t)min(255, max(0, (a_dv >> 7) + 128));
+    const uint32_t pair = du | (dv << 8);
+    // lane L<4 writes the header word, lane 4+j the descriptor dword j = pair[2j] | pair[2j+1]<<16
+    const int32_t lane = tid & 63, gbase = lane & ~15;
+    const int32_t j = (k >= 4) ? (k - 4) : 0;
+    const uint32_t lo = __shfl(pair, gbase + 2 * j), hi = __shfl(pair, gbase + 2 * j + 1);
+    uint32_t word;
+    if (k == 0) word = (uint32_t)(u * g.scale);
+    else if (k == 1) word = (uint32_t)(v * g.scale);
+    else if (k == 2) word = 0;  // val is zeroed on packing (matcher.cpp:667)
+    else if (k == 3) word = (uint32_t)c;
+    else word = lo | (hi << 16);
+    const int32_t fi = base + f;
+    if (live && k < 12 && fi < cap) out[(int64_t)fi * 12 + k] = (int32_t)word;
+  }
+}
+
+// --------------------------------------------------------------------- planes
+// Gradient / response planes on the valid interior, 0 elsewhere -- only for the
+// optional I_du/I_dv outputs of computeFeatures and for vh_filters; the
+// detection path never materialises them.
+__global__ void planes_kernel(const uint8_t *__restrict__ I, int32_t bpl, int32_t H,
+                              uint8_t *__restrict__ du, uint8_t *__restrict__ dv,
+                              int16_t *__restrict__ f1, int16_t *__restrict__ f2) {
+  const int32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= bpl) return;
+  const int64_t o = (int64_t)y * bpl + x;
+  int32_t r_du = 0, r_dv = 0, r_f1 = 0, r_f2 = 0;
+  if (x >= 2 && x <= bpl - 3 && y >= 2 && y <= H - 3) {
+    int32_t a_du = 0, a_dv = 0, a_f2 = 0, s5 = 0, s3 = 0, ctr = 0;
+#pragma unroll
+    for (int32_t r = 0; r < 5; r++) {
+      const uint8_t *p = I + (int64_t)(y + r - 2) * bpl + (x - 2);
+      const int32_t a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+      const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
+      const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
+      const int32_t cw = (r < 2) ? 1 : (r == 2 ? 0 : -1);
+      a_du += sw * (a + 2 * b - 2 * d - e);
+      a_dv += dw * (a + 4 * b + 6 * c + 4 * d + e);
+      a_f2 += cw * (a + b - d - e);
+      s5 += a + b + c + d + e;
+      if (r >= 1 && r <= 3) s3 += b + c + d;
+      if (r == 2) ctr = c;
+    }
+    r_du = min(255, max(0, (a_du >> 7) + 128));
+    r_dv = min(255, max(0, (a_dv >> 7) + 128));
+    r_f2 = a_f2;
+    if (x >= 3 && y >= 3) r_f1 = -s5 + 2 * s3 + 7 * ctr;
+  }
+  if (du) du[o] = (uint8_t)r_du;
+  if (dv) dv[o] = (uint8_t)r_dv;
+  if (f1) f1[o] = (int16_t)r_f1;
+  if (f2) f2[o] = (int16_t)r_f2;
+}
+
+}  // namespace
+
+void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipStream_t st) {
+  dim3 grid((g.bplm + 255) / 256, g.Hm, src.S * src.ncam);
+  hipLaunchKernelGGL(half_res_kernel, grid, dim3(256), 0, st, src, dst, g);
+}
+
+void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, int32_t *chunk_count,
+                          hipStream_t st) {
+  if (g.nblocks <= 0) return;
+  dim3 grid((g.nbx + g.tbx - 1) / g.tbx, (g.nby + g.tby - 1) / g.tby, im.S * im.ncam);
+  const size_t lds = (size_t)g.IH * g.IWp + 2 * (size_t)g.FH * g.FWp * sizeof(int16_t);
+  hipLaunchKernelGGL(detect_nms_kernel, grid, dim3(256), lds, st, im, g, rec, chunk_count);
+}
+
+void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t *rec,
+                             const int32_t *chunk_count, int32_t *feat, int32_t *count, int32_t cap,
+                             hipStream_t st) {
+  if (g.nblocks <= 0) return;
+  dim3 grid(g.nchunks, im.S * im.ncam);
+  hipLaunchKernelGGL(emit_features_kernel, grid, dim3(256), 0, st, im, g, rec, chunk_count, feat, count,
+                     cap);
+}
+
+void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
+                      int16_t *f1, int16_t *f2, hipStream_t st) {
+  dim3 grid((bpl + 255) / 256, H);
+  hipLaunchKernelGGL(planes_kernel, grid, dim3(256), 0, st, img, bpl, H, du, dv, f1, f2);
+}

@@ -1,0 +1,256 @@
+// kernels_match.hip -- binned 32-byte SAD matching on gfx950.
+//
+// Replaces Matcher::findMatch (reference src/matcher.cpp:216-272) and the
+// circle-match compositions of Matcher::matching (src/matcher.cpp:274-344).
+//
+// Restructuring relative to the reference (results identical):
+//  * The reference calls findMatch on demand along each match chain.  findMatch
+//    is a pure function of (query feature, candidate set), so here every pass
+//    of a chain is evaluated for ALL features of its query set at once
+//    (`match`), and the chains are then followed by table look-ups (`chain`).
+//  * Mapping: one LANE per QUERY, one wavefront per tile of <= 64 bin-ordered
+//    queries of one (class, u-bin) column.  The candidate stream is then
+//    wave-uniform: all 64 lanes walk the same bin range in the same order, the
+//    candidate record is fetched once per wave (scalar/broadcast load) and the
+//    SAD is 8 v_sad_u8 per lane with no cross-lane reduction at all.  Because
+//    positions in bin order ARE the reference's visiting order, its first-minimum
+//    tie-break (strict `<`, src/matcher.cpp:264) is simply "keep the earlier".
+//  * Each lane applies the reference's accept test on its own window
+//    (src/matcher.cpp:249); the wave only walks the union of its lanes' bin
+//    ranges (src/matcher.cpp:237-240), which never changes a lane's result
+//    because a candidate inside a lane's window always lies inside that lane's
+//    bin range.
+#include "vh_dev.h"
+
+namespace {
+
+__device__ __forceinline__ int32_t wave_min(int32_t v) {
+#pragma unroll
+  for (int32_t d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ int32_t wave_max(int32_t v) {
+#pragma unroll
+  for (int32_t d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+  return v;
+}
+
+__device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) {
+  return __builtin_amdgcn_sad_u8(a, b, acc);  // v_sad_u8: 4 byte-wise |a-b| summed into acc
+}
+
+__global__ void __launch_bounds__(256)
+match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
+  const int32_t pass = blockIdx.y, stream = blockIdx.z;
+  const int32_t lane = threadIdx.x & 63;
+  const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
+  const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
+  const int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (tile >= s.tile_cnt[qset]) return;
+  const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
+  const int32_t q0 = __builtin_amdgcn_readfirstlane(t.x), q1 = __builtin_amdgcn_readfirstlane(t.y);
+  const int32_t c = __builtin_amdgcn_readfirstlane(t.z);
+
+  const uint32_t *__restrict__ quv = s.s_uv + (int64_t)qset * s.cap;
+  const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
+  const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
+  const uint32_t *__restrict__ cuv = s.s_uv + (int64_t)cset * s.cap;
+  const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
+  const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
+  const int32_t *__restrict__ cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
+
+  const int32_t q = q0 + lane;
+  const bool valid = q < q1;
+  const int32_t ql = valid ? q : q0;
+  const uint32_t uv1 = quv[ql];
+  const uint4 a0 = qdesc[2 * (int64_t)ql], a1 = qdesc[2 * (int64_t)ql + 1];
+  const int32_t u1 = uv1 & 0xFFFF, v1 = uv1 >> 16;
+  const int32_t rv = a.pass[pass].flow ? a.radius : a.disp_tol;
+  // search window (matcher.cpp:231-234; stereo: v narrowed to +-disp_tolerance)
+  const int32_t u_lo = u1 - a.radius, u_hi = u1 + a.radius, v_lo = v1 - rv, v_hi = v1 + rv;
+  // bins of interest (matcher.cpp:237-240); for x<0 the clamp to 0 makes the
+  // truncating division equivalent to the reference's floor
+  int32_t ub_lo = min(max(u_lo, 0) / s.binsize, s.ubn - 1), ub_hi = min(max(u_hi, 0) / s.binsize, s.ubn - 1);
+  int32_t vb_lo = min(max(v_lo, 0) / s.binsize, s.vbn - 1), vb_hi = min(max(v_hi, 0) / s.binsize, s.vbn - 1);
+  if (!valid) { ub_lo = 0x7FFFFFFF; vb_lo = 0x7FFFFFFF; ub_hi = -1; vb_hi = -1; }
+  const int32_t UB0 = __builtin_amdgcn_readfirstlane(wave_min(ub_lo));
+  const int32_t UB1 = __builtin_amdgcn_readfirstlane(wave_max(ub_hi));
+  const int32_t VB0 = __builtin_amdgcn_readfirstlane(wave_min(vb_lo));
+  const int32_t VB1 = __builtin_amdgcn_readfirstlane(wave_max(vb_hi));
+
+  uint32_t best_cost = 0x7FFFFFFFu;  // reference: min_cost = 10000000 > any SAD (<= 8160)
+  int32_t best_pos = -1;
+  for (int32_t ub = UB0; ub <= UB1; ub++) {
+    const int32_t row = (c * s.ubn + ub) * s.vbn;
+    const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
+    const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + VB1 + 1]);
+    for (int32_t p = p0; p < p1; p++) {
+      const uint32_t uv2 = cuv[p];
+      const uint4 b0 = cdesc[2 * (int64_t)p], b1 = cdesc[2 * (int64_t)p + 1];
+      const int32_t u2 = uv2 & 0xFFFF, v2 = uv2 >> 16;
+      const bool in = (u2 >= u_lo) & (u2 <= u_hi) & (v2 >= v_lo) & (v2 <= v_hi);  // matcher.cpp:249
+      uint32_t sad = sad4(a0.x, b0.x, 0);
+      sad = sad4(a0.y, b0.y, sad);
+      sad = sad4(a0.z, b0.z, sad);
+      sad = sad4(a0.w, b0.w, sad);
+      sad = sad4(a1.x, b1.x, sad);
+      sad = sad4(a1.y, b1.y, sad);
+      sad = sad4(a1.z, b1.z, sad);
+      sad = sad4(a1.w, b1.w, sad);
+      if (in && sad < best_cost) { best_cost = sad; best_pos = p; }  // strict <: first minimum wins
+    }
+  }
+  if (valid) {
+    // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
+    const int32_t r = (best_pos >= 0) ? cidx[best_pos] : 0;
+    best[((int64_t)stream * 4 + pass) * s.cap + qidx[q]] = r;
+  }
+}
+
+// ---------------------------------------------------------------------- chain
+// Follows the circle of each driving feature through the per-pass tables and
+// records the index tuple (i1p,i2p,i1c,i2c), or z=-2 when the circle does not
+// close / the disparity test fails.
+//   flow   (matcher.cpp:308-336): 1c ->1p ->1c
+//   stereo (stock libviso2): 1c ->2c ->1c, u1c >= u2c
+//   quad   (stock libviso2): 1p ->2p ->2c ->1c ->1p,
+//                                             u1p >= u2p and u1c >= u2c
+// For flow the reference additionally keeps only the FIRST match per pixel of
+// the current image (mask M, matcher.cpp:331-334): every closing feature bids
+// for its pixel with atomicMax(epoch<<20 | (0xFFFFF - i1c)); the lowest i1c of
+// this epoch wins, and no clearing between frames is needed.
+__global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int32_t *__restrict__ best,
+                             int4 *__restrict__ chain, uint32_t *__restrict__ mask, uint32_t epoch) {
+  const int32_t stream = blockIdx.y;
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t set1p = vh_role_set(a.S, a.pair_cur, stream, 0), set2p = vh_role_set(a.S, a.pair_cur, stream, 1);
+  const int32_t set1c = vh_role_set(a.S, a.pair_cur, stream, 2), set2c = vh_role_set(a.S, a.pair_cur, stream, 3);
+  const int32_t n1p = min(s.count[set1p], s.cap), n2p = min(s.count[set2p], s.cap);
+  const int32_t n1c = min(s.count[set1c], s.cap), n2c = min(s.count[set2c], s.cap);
+  const int32_t *__restrict__ T = best + (int64_t)stream * 4 * s.cap;
+  const int64_t cap = s.cap;
+  int4 *__restrict__ out = chain + (int64_t)stream * s.cap;
+  if (method == 0) {
+    if (i >= n1c) return;
+    int4 r = make_int4(-1, -1, -2, -1);
+    if (n1p > 0) {
+      const int32_t i1p = T[0 * cap + i];
+      const int32_t i1c2 = T[1 * cap + i1p];
+      if (i1c2 == i) {
+        r = make_int4(i1p, -1, i, -1);
+        const int32_t *f = s.feat + ((int64_t)set1c * s.cap + i) * 12;
+        atomicMax(&mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]],
+                  (epoch << 20) | (0xFFFFFu - (uint32_t)i));
+      }
+    }
+    out[i] = r;
+  } else if (method == 1) {
+    if (i >= n1c) return;
+    int4 r = make_int4(-1, -1, -2, -1);
+    if (n2c > 0) {
+      const int32_t i2c = T[0 * cap + i];
+      const int32_t i1c2 = T[1 * cap + i2c];
+      const int32_t u1c = s.feat[((int64_t)set1c * s.cap + i) * 12], u2c = s.feat[((int64_t)set2c * s.cap + i2c) * 12];
+      if (i1c2 == i && u1c >= u2c) r = make_int4(-1, -1, i, i2c);
+    }
+    out[i] = r;
+  } else {
+    if (i >= n1p) return;
+    int4 r = make_int4(-1, -1, -2, -1);
+    if (n2p > 0 && n1c > 0 && n2c > 0) {
+      const int32_t i2p = T[0 * cap + i];
+      const int32_t i2c = T[1 * cap + i2p];
+      const int32_t i1c = T[2 * cap + i2c];
+      const int32_t i1p2 = T[3 * cap + i1c];
+      const int32_t u1p = s.feat[((int64_t)set1p * s.cap + i) * 12], u2p = s.feat[((int64_t)set2p * s.cap + i2p) * 12];
+      const int32_t u1c = s.feat[((int64_t)set1c * s.cap + i1c) * 12], u2c = s.feat[((int64_t)set2c * s.cap + i2c) * 12];
+      if (i1p2 == i && u1p >= u2p && u1c >= u2c) r = make_int4(i, i2p, i1c, i2c);
+    }
+    out[i] = r;
+  }
+}
+
+// --------------------------------------------------------------- emit_matches
+// One workgroup per stream: ordered compaction of the closed circles into
+// p_match records (48 B, src/matcher.h:89-104), in ascending order of the
+// driving feature index as the reference's loops emit them.
+__global__ void __launch_bounds__(1024)
+emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restrict__ chain,
+                    const uint32_t *__restrict__ mask, uint32_t epoch, float *__restrict__ matches,
+                    int32_t mcap, int32_t *__restrict__ match_count) {
+  __shared__ int32_t sWave[16];
+  __shared__ int32_t sTotal;
+  const int32_t stream = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int32_t sets[4];
+#pragma unroll
+  for (int32_t r = 0; r < 4; r++) sets[r] = vh_role_set(a.S, a.pair_cur, stream, r);
+  const int32_t drive = (method == 2) ? sets[0] : sets[2];
+  const int32_t n = min(s.count[drive], s.cap);
+  const int4 *__restrict__ ch = chain + (int64_t)stream * s.cap;
+  float *__restrict__ out = matches + (int64_t)stream * mcap * 12;
+  if (tid == 0) sTotal = 0;
+  __syncthreads();
+  for (int32_t i0 = 0; i0 < n; i0 += 1024) {
+    const int32_t i = i0 + tid;
+    int4 r = make_int4(-1, -1, -2, -1);
+    if (i < n) r = ch[i];
+    bool keep = r.z >= 0;
+    uint32_t rec[12];
+#pragma unroll
+    for (int32_t k = 0; k < 12; k++) rec[k] = (k % 3 == 2) ? 0xFFFFFFFFu : __float_as_uint(-1.0f);
+    if (keep) {
+      const int32_t idx[4] = {r.x, r.y, r.z, r.w};
+      int32_t u1c = 0, v1c = 0;
+#pragma unroll
+      for (int32_t k = 0; k < 4; k++) {
+        if (idx[k] >= 0) {
+          const int32_t *f = s.feat + ((int64_t)sets[k] * s.cap + idx[k]) * 12;
+          rec[3 * k + 0] = __float_as_uint((float)f[0]);
+          rec[3 * k + 1] = __float_as_uint((float)f[1]);
+          if (k == 2) { u1c = f[0]; v1c = f[1]; }
+        }
+        rec[3 * k + 2] = (uint32_t)idx[k];
+      }
+      if (method == 0)  // first writer per pixel (matcher.cpp:331)
+        keep = mask[(int64_t)stream * s.W * s.H + (int64_t)v1c * s.W + u1c] == ((epoch << 20) | (0xFFFFFu - (uint32_t)r.z));
+    }
+    // workgroup exclusive scan of keep
+    const uint64_t bal = __ballot(keep);
+    const int32_t before = __popcll(bal & ((1ull << lane) - 1));
+    if (lane == 0) sWave[w] = __popcll(bal);
+    __syncthreads();
+    int32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int32_t k = 0; k < 16; k++) { const int32_t c = sWave[k]; if (k < w) woff += c; tot += c; }
+    const int32_t base = sTotal;
+    const int32_t pos = base + woff + before;
+    if (keep && pos < mcap) {
+      uint4 *o = (uint4 *)(out + (int64_t)pos * 12);
+      o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+      o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+      o[2] = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+    }
+    __syncthreads();
+    if (tid == 0) sTotal = base + tot;
+    __syncthreads();
+  }
+  if (tid == 0) match_count[stream] = sTotal;
+}
+
+}  // namespace
+
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
+  dim3 grid((s.max_tiles + 3) / 4, a.npass, a.S);
+  hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, st, s, a, best);
+}
+void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
+                     int4 *chain, uint32_t *mask, uint32_t epoch, hipStream_t st) {
+  dim3 grid((s.cap + 255) / 256, a.S);
+  hipLaunchKernelGGL(chain_kernel, grid, dim3(256), 0, st, s, a, method, best, chain, mask, epoch);
+}
+void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
+                            const uint32_t *mask, uint32_t epoch, void *matches, int32_t mcap,
+                            int32_t *match_count, hipStream_t st) {
+  hipLaunchKernelGGL(emit_matches_kernel, dim3(a.S), dim3(1024), 0, st, s, a, method, chain, mask, epoch,
+                     (float *)matches, mcap, match_count);
+}

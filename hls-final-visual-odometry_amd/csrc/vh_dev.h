@@ -1,0 +1,126 @@
+// vh_dev.h -- shared host/device declarations of the gfx950 detect+match engine.
+//
+// Data layout in HBM (all arrays are flat, one allocation per kind, indexed by
+// a *set id* or an *image id* so that one kernel launch covers every camera
+// stream of a group):
+//
+//   image id  = stream*2 + cam                      (cam 0 = left, 1 = right)
+//   set id    = pair*(2*S) + stream*2 + cam         (pair = ring slot 0/1; the
+//               current/previous roles swap by flipping `pair`, never by copy:
+//               reference ring buffer src/matcher.cpp:64-79)
+//
+//   feat      [set][cap][12] int32   the reference's packed record
+//                                    {u,v,0,c,d1..d8} (src/matcher.cpp:663-671)
+//   s_uv      [set][cap]     uint32  u | v<<16, in *bin order*
+//   s_idx     [set][cap]     int32   original feature index of that position
+//   s_desc    [set][cap][8]  uint32  32-byte descriptor, in bin order
+//   bin_start [set][nbins+1] int32   CSR over bins, bin = (c*ubn+ub)*vbn+vb
+//                                    (u-bin major: the iteration order of
+//                                    Matcher::findMatch, src/matcher.cpp:243-246)
+//   rec       [image][nblocks] u64   per NMS block 4 x u16 position codes
+//   best      [stream][pass][cap] int32  findMatch result for every query
+//   matches   [stream][mcap] p_match (48 B, src/matcher.h:89-104)
+#ifndef VH_DEV_H
+#define VH_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VH_MARGIN 7          // src/matcher.cpp:38
+#define VH_CHUNK 1024        // NMS blocks per emit workgroup
+#define VH_WAVE 64
+#define VH_NO_CODE 0xFFFFu
+
+struct VhGeom {
+  // full-resolution image
+  int32_t W, H, bpl;
+  // matching-resolution image (== full unless half_resolution)
+  int32_t Wm, Hm, bplm;
+  int32_t scale;            // 1, or 2 with half_resolution (src/matcher.cpp:647-649)
+  int32_t n, tau;           // nms_n, nms_tau
+  int32_t nbx, nby, nblocks, nchunks;
+  int32_t tbx, tby;         // NMS blocks per detect tile
+  int32_t FW, FH, IW, IH;   // filter-response tile / image tile extents (pixels)
+  int32_t IWp, FWp;         // padded LDS row pitches
+};
+
+struct VhSets {
+  int32_t *feat;
+  uint32_t *s_uv;
+  int32_t *s_idx;
+  uint32_t *s_desc;
+  int32_t *bin_start;
+  int32_t *hist;
+  int32_t *cursor;
+  int32_t *tmp_idx;
+  int32_t *count;
+  int4 *tiles;       // [set][max_tiles] {q0, q1, class, ub}
+  int32_t *tile_cnt; // [set]
+  int32_t cap, nbins, ubn, vbn, binsize, max_tiles;
+  int32_t W, H;      // dims_c of the matcher (full resolution)
+};
+
+struct VhPass {
+  int32_t qset;  // role (VH_SET_*) providing the queries
+  int32_t cset;  // role providing the candidates
+  int32_t flow;  // 1: +-radius in v; 0: +-disp_tolerance (stereo search)
+};
+
+struct VhMatchArgs {
+  VhPass pass[4];
+  int32_t npass;
+  int32_t pair_cur;  // ring slot holding the current frame
+  int32_t S;
+  int32_t radius, disp_tol;
+};
+
+__host__ __device__ inline int32_t vh_set_id(int32_t S, int32_t pair, int32_t stream, int32_t cam) {
+  return pair * (2 * S) + stream * 2 + cam;
+}
+// role: 0=1p 1=2p 2=1c 3=2c
+__host__ __device__ inline int32_t vh_role_set(int32_t S, int32_t pair_cur, int32_t stream, int32_t role) {
+  const int32_t pair = (role >= 2) ? pair_cur : (pair_cur ^ 1);
+  return vh_set_id(S, pair, stream, role & 1);
+}
+
+struct VhImages {
+  const uint8_t *base[2];  // left / right image of stream 0
+  int64_t stride;          // bytes between consecutive streams
+  int32_t ncam;            // 1 (mono / flow) or 2 (stereo)
+  int32_t S;               // streams
+  int32_t pair_cur;        // ring slot the new features are written to
+};
+// image id = stream*ncam + cam
+__host__ __device__ inline const uint8_t *vh_image_ptr(const VhImages &im, int32_t id) {
+  const int32_t s = id / im.ncam, cam = id % im.ncam;
+  return im.base[cam] + (int64_t)s * im.stride;
+}
+__host__ __device__ inline int32_t vh_image_set(const VhImages &im, int32_t id) {
+  return vh_set_id(im.S, im.pair_cur, id / im.ncam, id % im.ncam);
+}
+
+// ---- launchers (defined in the kernels_*.hip files) ------------------------
+void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipStream_t st);
+void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, int32_t *chunk_count,
+                          hipStream_t st);
+void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t *rec,
+                             const int32_t *chunk_count, int32_t *feat, int32_t *count, int32_t cap,
+                             hipStream_t st);
+void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
+                      int16_t *f1, int16_t *f2, hipStream_t st);
+
+void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
+void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
+void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
+void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
+void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, int32_t *list_ref,
+                         hipStream_t st);
+
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
+void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
+                     int4 *chain, uint32_t *mask, uint32_t epoch, hipStream_t st);
+void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
+                            const uint32_t *mask, uint32_t epoch, void *matches, int32_t mcap,
+                            int32_t *match_count, hipStream_t st);
+
+#endif

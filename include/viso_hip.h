@@ -1,0 +1,212 @@
+/*
+ * viso_hip.h -- C ABI of libviso_hip.so: the MI355X (gfx950) implementation of
+ * the libviso2-style feature detection + matching hot path of
+ * Chang-Tun-Yu/HLS-final-Visual-Odometry.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types.  Each entry point names the reference interface it replaces
+ * (file:line relative to the reference tree).  include/viso_hip_matcher.hpp
+ * wraps these calls in a C++ `Matcher` class with the reference's public
+ * method set, so src/viso_stereo.cpp / src/viso_mono.cpp compile against it
+ * unchanged.
+ *
+ * All compute runs in hand-written HIP kernels; there is no CPU fallback.
+ * Every call returns VH_OK (0) or a negative VH_ERR_* code; nothing throws.
+ *
+ * Threading: a handle is not re-entrant (neither is the reference's Matcher);
+ * use one handle per camera stream and one host thread per handle.
+ */
+#ifndef VISO_HIP_H
+#define VISO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+#define VH_OK 0
+#define VH_ERR_INVALID_ARG (-1)  /* null pointer, bad dims (reference: cerr "Image dimension mismatch", src/matcher.cpp:59-62) */
+#define VH_ERR_NO_DEVICE (-2)    /* no HIP device / kernel image for this GPU: the product path never falls back to the CPU */
+#define VH_ERR_HIP (-3)          /* a HIP runtime call failed; see vh_last_error() */
+#define VH_ERR_CAPACITY (-4)     /* more features/matches than the capacity given (the reference overruns POINT_L silently, src/matcher.cpp:332) */
+#define VH_ERR_UNSUPPORTED (-5)  /* parameter outside the supported envelope (see vh_create) */
+#define VH_ERR_STATE (-6)        /* e.g. match before two frames were pushed */
+
+/* ---- types --------------------------------------------------------------- */
+
+/* POD mirror of Matcher::parameters, field for field (src/matcher.h:45-72). */
+typedef struct vh_params {
+  int32_t nms_n;                  /* non-max-suppression: min. distance between maxima (pixels) */
+  int32_t nms_tau;                /* non-max-suppression: interest point peakiness threshold */
+  int32_t match_binsize;          /* matching bin width/height */
+  int32_t match_radius;           /* matching radius (du/dv in pixels) */
+  int32_t match_disp_tolerance;   /* dv tolerance for stereo matches (pixels) */
+  int32_t outlier_disp_tolerance; /* accepted, unused by this path (as in the reference) */
+  int32_t outlier_flow_tolerance; /* accepted, unused by this path */
+  int32_t multi_stage;            /* 1 = also extract the sparse feature set (max1) */
+  int32_t half_resolution;        /* 1 = detect at half resolution, coordinates x2 */
+  int32_t refinement;             /* accepted, unused (absent from the reference) */
+  double f, cu, cv, base;         /* calibration (only for match prediction; unused) */
+} vh_params;
+
+/* Mirror of Matcher::p_match (src/matcher.h:89-104): 48 bytes, unused slots = -1. */
+typedef struct vh_p_match {
+  float u1p, v1p; int32_t i1p; /* previous left  */
+  float u2p, v2p; int32_t i2p; /* previous right */
+  float u1c, v1c; int32_t i1c; /* current  left  */
+  float u2c, v2c; int32_t i2c; /* current  right */
+} vh_p_match;
+
+/* Feature records are int32[12] = {u, v, 0, class, d1..d8} exactly as
+ * Matcher::computeFeatures packs them (src/matcher.cpp:663-671). */
+#define VH_FEATURE_WORDS 12
+
+/* Which ring-buffer feature set (vh_get_features). */
+#define VH_SET_1P 0 /* previous left  */
+#define VH_SET_2P 1 /* previous right */
+#define VH_SET_1C 2 /* current  left  */
+#define VH_SET_2C 3 /* current  right */
+
+/* Matching method (Matcher::matchFeatures, src/matcher.h:124-128). */
+#define VH_METHOD_FLOW 0
+#define VH_METHOD_STEREO 1
+#define VH_METHOD_QUAD 2
+
+typedef struct vh_matcher vh_matcher; /* one camera stream (== one Matcher)      */
+typedef struct vh_group vh_group;     /* S independent streams stepped together  */
+
+/* ---- library ------------------------------------------------------------- */
+int32_t vh_abi_version(void);
+/* Number of visible HIP devices, or VH_ERR_NO_DEVICE. */
+int32_t vh_device_count(void);
+const char *vh_error_string(int32_t code);
+/* Text of the last failing HIP call on this thread ("" if none). */
+const char *vh_last_error(void);
+/* Matcher::parameters() defaults (src/matcher.h:60-71). */
+void vh_default_params(vh_params *p);
+
+/* ---- one stream: the Matcher surface ----------------------------------- */
+
+/* Matcher::Matcher(parameters) (src/matcher.cpp:32-41) on HIP device `device`.
+ * Envelope: 1 <= nms_n <= 64, match_binsize >= 1, match_radius >= 0,
+ * images up to 16384 x 16384.  max_features/max_matches = 0 select the
+ * worst-case capacity for the pushed image size (4 per NMS block). */
+int32_t vh_create(const vh_params *p, int32_t device, vh_matcher **out);
+int32_t vh_create_ex(const vh_params *p, int32_t device, int32_t max_features,
+                     int32_t max_matches, vh_matcher **out);
+/* Matcher::~Matcher (src/matcher.cpp:44-49). */
+void vh_destroy(vh_matcher *m);
+/* Matcher::setIntrinsics (src/matcher.h:81-86). */
+int32_t vh_set_intrinsics(vh_matcher *m, double f, double cu, double cv, double base);
+
+/* Matcher::pushBack(I1,I2,dims,replace) (src/matcher.h:116, src/matcher.cpp:51-91)
+ * with the stock computeFeatures behind it (src/matcher.cpp:585-672).
+ * I1/I2: host images, row-major u8, stride dims[2] >= dims[0]; I2 may be NULL
+ * (mono/flow).  The images are borrowed for the duration of the call. */
+int32_t vh_push_back(vh_matcher *m, const uint8_t *I1, const uint8_t *I2,
+                     const int32_t dims[3], int32_t replace);
+/* Same, images already resident in device memory (e.g. a torch tensor's
+ * data_ptr); asynchronous on the handle's stream. */
+int32_t vh_push_back_device(vh_matcher *m, const void *dI1, const void *dI2,
+                            const int32_t dims[3], int32_t replace);
+
+/* Matcher::matchFeatures(method, Tr_delta) (src/matcher.h:128,
+ * src/matcher.cpp:93-111) with the stock Matcher::matching behind it
+ * (src/matcher.cpp:274-344).  Tr_delta16 (row-major 4x4) is accepted and
+ * ignored, as the reference does.  Does not run removeOutliers. */
+int32_t vh_match_features(vh_matcher *m, int32_t method, const double *Tr_delta16);
+
+/* Matcher::bucketFeatures (src/matcher.h:132, src/matcher.cpp:140-187):
+ * host-side post-processing of the current matches, LFSR shuffle included. */
+int32_t vh_bucket_features(vh_matcher *m, int32_t max_features, float bucket_width,
+                           float bucket_height);
+
+/* Matcher::getMatches (src/matcher.h:138-143).  *n receives the true count;
+ * at most cap records are written (VH_ERR_CAPACITY if n > cap). */
+int32_t vh_get_matches(vh_matcher *m, vh_p_match *out, int32_t cap, int32_t *n);
+/* The ring buffer's feature records (max2p/max2c in the reference,
+ * src/matcher.h:252): the parity contract includes descriptors. */
+int32_t vh_get_features(vh_matcher *m, int32_t which, int32_t *out12, int32_t cap, int32_t *n);
+/* Block until everything queued on the handle's stream has finished. */
+int32_t vh_synchronize(vh_matcher *m);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * handle's own.  Pass NULL to return to the internal stream. */
+int32_t vh_set_stream(vh_matcher *m, void *hip_stream);
+
+/* ---- stateless primitives (private members of the reference's Matcher) -- */
+
+/* Matcher::computeFeatures (src/matcher.h:209, src/matcher.cpp:585-672).
+ * max1/num1 (sparse set, multi_stage only), du/dv (matching-resolution
+ * gradient planes, stride dims_matching[2]) may be NULL.  num1/num2 return
+ * the true counts. */
+int32_t vh_compute_features(const vh_params *p, int32_t device, const uint8_t *I,
+                            const int32_t dims[3], int32_t *max1, int32_t cap1,
+                            int32_t *num1, int32_t *max2, int32_t cap2, int32_t *num2,
+                            uint8_t *du, uint8_t *dv);
+/* filter::sobel5x5 / blob5x5 / checkerboard5x5 (src/filter.h:80-96) on the
+ * valid interior; pixels outside it are 0.  Any output may be NULL. */
+int32_t vh_filters(int32_t device, const uint8_t *I, int32_t bpl, int32_t H, uint8_t *du,
+                   uint8_t *dv, int16_t *f1, int16_t *f2);
+/* Matcher::createIndexVector (src/matcher.cpp:194-214) flattened to CSR in the
+ * reference's bin numbering (c*v_bin_num+v_bin)*u_bin_num+u_bin:
+ * bin_start[4*ubn*vbn+1], list[n]. */
+int32_t vh_create_index(const vh_params *p, int32_t device, const int32_t dims[3],
+                        const int32_t *m, int32_t n, int32_t *bin_start, int32_t *list);
+/* Matcher::findMatch (src/matcher.cpp:216-272) for every query of set 1
+ * against set 2: best[i1] = min_ind.  flow=0 narrows v to
+ * +-match_disp_tolerance (stock libviso2 stereo search). */
+int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3],
+                     const int32_t *m1, int32_t n1, const int32_t *m2, int32_t n2,
+                     int32_t flow, int32_t *best);
+/* Matcher::matching (src/matcher.h:218, src/matcher.cpp:274-344) on
+ * caller-supplied feature arrays. Unused sets: NULL/0. */
+int32_t vh_match(const vh_params *p, int32_t device, const int32_t dims[3], int32_t method,
+                 const int32_t *m1p, int32_t n1p, const int32_t *m2p, int32_t n2p,
+                 const int32_t *m1c, int32_t n1c, const int32_t *m2c, int32_t n2c,
+                 vh_p_match *out, int32_t cap, int32_t *n);
+
+/* ---- S independent camera streams stepped together ---------------------- */
+/* The multi-stream configuration (one sequence per stream, no exchange
+ * between streams): every kernel launch covers all S streams, which is what
+ * fills an MI355X at KITTI image size.  Stream s of a group behaves exactly
+ * like its own vh_matcher. */
+int32_t vh_group_create(const vh_params *p, int32_t device, int32_t n_streams,
+                        int32_t max_features, int32_t max_matches, vh_group **out);
+void vh_group_destroy(vh_group *g);
+int32_t vh_group_streams(const vh_group *g);
+/* Device-resident images: stream s reads dI1 + s*stride_bytes (and dI2 + ...;
+ * dI2 may be NULL).  Asynchronous on the group's stream. */
+int32_t vh_group_push_back_device(vh_group *g, const void *dI1, const void *dI2,
+                                  int64_t stride_bytes, const int32_t dims[3],
+                                  int32_t replace);
+/* Host images, same addressing. */
+int32_t vh_group_push_back(vh_group *g, const uint8_t *I1, const uint8_t *I2,
+                           int64_t stride_bytes, const int32_t dims[3], int32_t replace);
+int32_t vh_group_match_features(vh_group *g, int32_t method);
+int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32_t cap,
+                             int32_t *n);
+int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_t *out12,
+                              int32_t cap, int32_t *n);
+/* Per-stream counts of the last step without copying records:
+ * n_features[4*S] (1p,2p,1c,2c per stream), n_matches[S]. Either may be NULL. */
+int32_t vh_group_get_counts(vh_group *g, int32_t *n_features, int32_t *n_matches);
+int32_t vh_group_synchronize(vh_group *g);
+int32_t vh_group_set_stream(vh_group *g, void *hip_stream);
+
+/* Kernel timing (HIP events recorded on the group's stream around every
+ * kernel launch while enabled).  vh_group_profile_read returns the
+ * accumulated milliseconds and launch count of kernel `name`
+ * ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill",
+ *  "bin_sort", "match", "chain", "emit_matches") since the last reset. */
+int32_t vh_group_profile_enable(vh_group *g, int32_t on);
+int32_t vh_group_profile_read(vh_group *g, const char *name, double *ms, int64_t *launches);
+int32_t vh_group_profile_reset(vh_group *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISO_HIP_H */
