@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frame-pairs/sec (detect + quad match), KITTI 1241x376.
+
+One "step" = one pass of the hot path over one batch of synthetic input: every
+camera stream of this rank's stream group receives one new stereo pair
+(pushBack: detect on 2 images) and is quad-matched against its previous pair
+(matchFeatures(2)).  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S]
+
+N>1 is launched by the driver through torch.distributed.run, one rank per GPU;
+ranks run independent streams (no data-path collective: the path partitions by
+camera sequence) and only the timing is reduced (MAX over ranks).
+
+Rank 0 prints ONE JSON line; see README/DESIGN.md for the `roofline` and
+`cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+METRIC = "stereo frame-pairs/sec (detect+match), KITTI 1241x376; matches bit-exact"
+W, H = 1241, 376
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNELS = ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill", "bin_sort",
+           "match", "chain", "emit_matches")
+
+
+def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
+    """[T][2][S][H][bpl] uint8: stream s follows sequence (seed 1 + (rank*S+s) % 8),
+    phase-shifted so that no two streams of a rank see identical frames."""
+    bpl = pkg.synth.bytes_per_line(W)
+    out = np.zeros((n_frames, 2, n_streams, H, bpl), np.uint8)
+    for s in range(n_streams):
+        gs = rank * n_streams + s
+        seed, phase = 1 + gs % 8, gs // 8
+        for t in range(n_frames):
+            k = t + phase
+            dx, dy = (5 * k) % 20, k % 20
+            out[t, 0, s] = pkg.synth.frame(W, H, dx, dy, 8, 1, seed)
+            out[t, 1, s] = pkg.synth.frame(W, H, dx + 12, dy, 8, 1, seed)
+    return out, bpl
+
+
+def cpu_baseline(ob, frames, dims, budget_s: float):
+    """The oracle (CPU port of the reference SSE path; flow bit-identical to the
+    reference, quad per SURVEY App. A.7) on a bounded sample of the SAME
+    workload: stream 0's consecutive stereo pairs, one thread."""
+    o = ob.Oracle()
+    p = ob.Params.default()
+    T = frames.shape[0]
+    prev = None
+    pairs = 0
+    results = []
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        t = k % T
+        cur = [o.compute_features(p, frames[t, c, 0], dims)[1] for c in (0, 1)]
+        if prev is not None:
+            results.append(o.matching(p, dims, 2, prev[0], prev[1], cur[0], cur[1]))
+            pairs += 1
+        prev = cur
+        k += 1
+        if pairs >= 3 and time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    # the first detect has no match: charge detect+match per pair
+    return pairs / dt, pairs, dt, results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", "64")),
+                    help="independent camera streams per GPU, stepped together")
+    ap.add_argument("--frames", type=int, default=8, help="distinct frames per stream kept in HBM")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = entry.load_package()
+    S, T = args.streams, args.frames
+    frames_np, bpl = make_frames(pkg, S, T, rank)
+    dims = [W, H, bpl]
+    frames = torch.from_numpy(frames_np).to(dev)  # resident in HBM before timing
+    stride = H * bpl
+
+    stream = torch.cuda.current_stream()
+    grp = pkg.StreamGroup(S, pkg.Params.default(), device=local_rank, max_features=32768, max_matches=32768)
+    grp.setStream(stream.cuda_stream)
+
+    def step(k):
+        t = k % T
+        grp.pushBackDevice(frames[t, 0].data_ptr(), frames[t, 1].data_ptr(), stride, dims, False)
+        grp.matchFeatures(pkg.METHOD_QUAD)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k = 0
+    for _ in range(args.warmup):
+        step(k); k += 1
+    grp.profileEnable(True)
+    grp.profileReset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(k); k += 1
+    fence()
+    dt = time.perf_counter() - t0
+    grp.profileEnable(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    # per-kernel device time over the timed region (HIP events on the launch stream)
+    prof = {}
+    for name in KERNELS:
+        ms, n = grp.profileRead(name)
+        if n:
+            prof[name] = {"ms_total": ms, "launches": n, "us_per_launch": 1e3 * ms / n}
+    nf, nm = grp.getCounts()
+    last = (k - 1) % T
+    got0 = grp.getMatches(0)
+
+    if rank == 0:
+        pairs = world * S * args.steps
+        value = pairs / dt
+        # algorithmic bytes per stereo pair: read 2 new images, write 2 new
+        # feature sets, the matcher reads all 4 sets once, write M matches
+        nfm = nf.astype(np.float64).mean(axis=0)
+        B_pair = 2 * bpl * H + 48 * (nfm[2] + nfm[3]) + 48 * nfm.sum() + 48 * float(nm.mean())
+        dom = max(prof, key=lambda n_: prof[n_]["ms_total"]) if prof else None
+        roofline = None
+        if dom:
+            sec = prof[dom]["us_per_launch"] * 1e-6
+            achieved = S * B_pair / sec / 1e9
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tj):
+                try:
+                    tr = json.load(open(tj))
+                    if tr.get("streams") == S and tr.get("kernel") == dom:
+                        traffic = tr.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": S * B_pair, "us_per_launch": prof[dom]["us_per_launch"],
+                        "note": "integer SAD search: v_sad_u8 issue-bound, not HBM-bound (DESIGN.md)"}
+        out = {
+            "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "KITTI 1241x376 stereo quad-match (prev/curr x L/R), default 50x50 bins",
+                       "streams_per_gpu": S, "frames_in_hbm": T, "features_per_image": float(nfm.mean()),
+                       "matches_per_pair": float(nm.mean()), "parallelism": f"{world}x independent stream groups"},
+            "roofline": roofline,
+            "kernels_us_per_launch": {n_: round(v["us_per_launch"], 2) for n_, v in prof.items()},
+        }
+        if not args.no_cpu:
+            ob = entry.load_oracle()
+            rate, n_pairs, secs, results = cpu_baseline(ob, frames_np, dims, args.cpu_seconds)
+            out["cpu_baseline"] = {"value": rate, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "sample": f"{n_pairs} consecutive stereo pairs of stream 0 (detect 2 images + quad match each), "
+                                             f"{secs:.1f} s, oracle/viso_oracle.c single thread"}
+            # the oracle as checker: stream 0's last GPU step must equal the CPU result for the same frames
+            o = ob.Oracle(); p = ob.Params.default()
+            prev_t = (last - 1) % T
+            f = [o.compute_features(p, frames_np[t_, c, 0], dims)[1] for t_ in (prev_t, last) for c in (0, 1)]
+            want = o.matching(p, dims, 2, *f)
+            out["parity_checked"] = bool(got0.tobytes() == want.tobytes())
+        print(json.dumps(out), flush=True)
+    grp.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own code -- TEST INFRASTRUCTURE.
+
+Runs only where /root/reference exists (this container): it drives
+oracle/_ref/libviso_ref.so -- the reference's src/matcher.cpp + src/filter.cpp
+compiled where they lie (oracle/Makefile target `_ref`) -- on frames from the
+deterministic generator (hls-final-visual-odometry_amd/synth.py)
+and stores inputs' parameters plus the reference's outputs.  The fixtures are
+data only (feature records, bin lists, match records, hashes); the images are
+re-generated from (W,H,dx,dy,blur,gain,seed) at test time.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name -> (W, H, blur, gain, seed, (dx,dy) of the current frame, params overrides)
+CASES = {
+    "small_default": (320, 160, 4, 1, 3, (3, 1), {}),
+    "small_nms3_tau30": (322, 131, 4, 1, 4, (2, 2), {"nms_n": 3, "nms_tau": 30}),
+    "small_nms1": (200, 120, 5, 1, 5, (1, 0), {"nms_n": 1, "nms_tau": 20}),
+    "small_bin20_r60": (300, 150, 4, 1, 6, (4, 1), {"match_binsize": 20, "match_radius": 60}),
+    "small_bin64_r37": (333, 177, 4, 2, 7, (2, 3), {"match_binsize": 64, "match_radius": 37}),
+    "small_half": (480, 240, 6, 1, 8, (4, 2), {"half_resolution": 1}),
+    "small_multi": (320, 200, 6, 1, 9, (3, 1), {"multi_stage": 1}),
+    "small_multi_half_n3": (480, 260, 6, 1, 10, (2, 2), {"multi_stage": 1, "half_resolution": 1, "nms_n": 3}),
+    "dense_gain4": (256, 128, 1, 4, 11, (1, 1), {}),
+}
+
+# Known-answer hashes only (SURVEY Appendix B sizes): arrays would be ~1.3 MB each.
+HASH_CASES = {
+    "kitti_1241x376": (1241, 376, 8, 1, 1, (5, 1), {}),
+    "seq_1024x284": (1024, 284, 8, 1, 1, (5, 1), {}),
+}
+
+
+def run_case(ref, ob, synth, W, H, blur, gain, seed, pan, over):
+    p = ob.Params.default(**over)
+    bpl = synth.bytes_per_line(W)
+    dims = [W, H, bpl]
+    Ip = synth.frame(W, H, 0, 0, blur, gain, seed)
+    Ic = synth.frame(W, H, pan[0], pan[1], blur, gain, seed)
+    m1p, m2p = ref.compute_features(p, Ip, dims)
+    m1c, m2c, du, dv = ref.compute_features(p, Ic, dims, planes=True)
+    pm = ref.matching_flow(p, dims, m2p, m2c)
+    bs, lst = ref.create_index(p, m2c, dims)
+    fwd = ref.match_all(p, dims, m2c, m2p)
+    return p, dims, dict(max1p=m1p, max2p=m2p, max1c=m1c, max2c=m2c, du=du, dv=dv, p_match=pm,
+                         bin_start=bs, bin_list=lst, fwd=fwd)
+
+
+def main():
+    pkg = entry.load_package()
+    ob = entry.load_oracle()
+    ob.build(ref=True)
+    ref = ob.Reference()
+    o = ob.Oracle()
+    synth = pkg.synth
+    os.makedirs(GOLDEN, exist_ok=True)
+
+    for name, (W, H, blur, gain, seed, pan, over) in CASES.items():
+        p, dims, r = run_case(ref, ob, synth, W, H, blur, gain, seed, pan, over)
+        # gradient planes: keep only the rows/cols descriptors can touch, as a hash
+        # plus one 16x16 patch for eyeballing
+        np.savez_compressed(
+            os.path.join(GOLDEN, name + ".npz"),
+            gen=np.array([W, H, blur, gain, seed, pan[0], pan[1]], np.int32),
+            params=np.array([[k, v] for k, v in over.items()], dtype="U32").reshape(-1, 2),
+            max1p=r["max1p"], max2p=r["max2p"], max1c=r["max1c"], max2c=r["max2c"],
+            p_match=r["p_match"], bin_start=r["bin_start"], bin_list=r["bin_list"], fwd=r["fwd"],
+            du_interior_fnv=np.uint64(o.fnv(np.ascontiguousarray(r["du"][2:-2, 2:r["du"].shape[1] - 16]))),
+            dv_interior_fnv=np.uint64(o.fnv(np.ascontiguousarray(r["dv"][2:-2, 2:r["dv"].shape[1] - 16]))))
+        print(f"{name}: n2p={len(r['max2p'])} n2c={len(r['max2c'])} n1c={len(r['max1c'])} matches={len(r['p_match'])}")
+
+    hashes = {}
+    for name, (W, H, blur, gain, seed, pan, over) in HASH_CASES.items():
+        p, dims, r = run_case(ref, ob, synth, W, H, blur, gain, seed, pan, over)
+        hashes[name] = dict(
+            gen=np.array([W, H, blur, gain, seed, pan[0], pan[1]], np.int32),
+            n2p=len(r["max2p"]), n2c=len(r["max2c"]), n_match=len(r["p_match"]),
+            fnv_max2p=np.uint64(o.fnv(r["max2p"])), fnv_max2c=np.uint64(o.fnv(r["max2c"])),
+            fnv_p_match=np.uint64(o.fnv(r["p_match"])), fnv_fwd=np.uint64(o.fnv(r["fwd"])),
+            class_hist=np.bincount(r["max2c"][:, 3], minlength=4).astype(np.int32),
+            head_max2c=r["max2c"][:32], head_p_match=r["p_match"][:32])
+        print(f"{name}: n2p={hashes[name]['n2p']} n2c={hashes[name]['n2c']} matches={hashes[name]['n_match']} "
+              f"fnv(max2c)={int(hashes[name]['fnv_max2c']):016x} fnv(p_match)={int(hashes[name]['fnv_p_match']):016x}")
+    flat = {f"{k}__{kk}": vv for k, v in hashes.items() for kk, vv in v.items()}
+    np.savez_compressed(os.path.join(GOLDEN, "known_answers.npz"), **flat)
+
+    # findMatch with the u_,v_ distance term (src/matcher.cpp:257-262), which no
+    # caller in the reference uses: pin the oracle's restatement of it.
+    W, H, blur, gain, seed, pan, over = CASES["small_default"]
+    p, dims, r = run_case(ref, ob, synth, W, H, blur, gain, seed, pan, over)
+    prior = ref.match_all(p, dims, r["max2c"], r["max2p"], u_=150.0, v_=70.0)
+    np.savez_compressed(os.path.join(GOLDEN, "find_match_prior.npz"), u_=150.0, v_=70.0, best=prior)
+
+    # bucketFeatures + LFSR shuffle (src/matcher.cpp:113-187) on the 1024x284
+    # flow matches (the only size its fixed buckets[126][256] array is built for)
+    W, H, blur, gain, seed, pan, over = HASH_CASES["seq_1024x284"]
+    p, dims, r = run_case(ref, ob, synth, W, H, blur, gain, seed, pan, over)
+    bk = {}
+    for mf, bw, bh in ((2, 50.0, 50.0), (1, 50.0, 50.0), (5, 64.0, 48.0), (300, 50.0, 50.0)):
+        out = ref.bucket_features(p, r["p_match"], mf, bw, bh)
+        bk[f"out_{mf}_{int(bw)}_{int(bh)}"] = out
+        print(f"bucket({mf},{bw},{bh}): {len(r['p_match'])} -> {len(out)}")
+    np.savez_compressed(os.path.join(GOLDEN, "bucket_1024x284.npz"), **bk)
+
+
+if __name__ == "__main__":
+    main()

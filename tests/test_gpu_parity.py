@@ -1,0 +1,385 @@
+"""GPU suite: the HIP path, called through the C ABI (libviso_hip.so), must be
+bit-identical to the oracle -- and to the golden vectors generated from the
+reference's own code -- on the same inputs.  Integer/byte work: the bar is
+exact equality everywhere (no tolerances)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def feats_for(oracle, p, dims, imgs):
+    return [oracle.compute_features(p, im, dims)[1] for im in imgs]
+
+
+# ------------------------------------------------------------------ a2-a4: filters
+@pytest.mark.parametrize("shape", [(64, 48), (333, 100), (1248, 376)])
+def test_filters_planes(shape, pkg, oracle, gpu):
+    bpl, H = shape
+    rng = np.random.default_rng(bpl)
+    img = rng.integers(0, 256, (H, bpl), dtype=np.uint8)
+    got = pkg.filters(img)
+    want = oracle.filters(img)
+    for name, a, b in zip(("du", "dv", "f1", "f2"), got, want):
+        assert np.array_equal(a, b), name
+
+
+# ------------------------------------------------ a1,a5-a7,a12: computeFeatures (golden)
+@pytest.mark.parametrize("name", golden_names())
+def test_compute_features_golden(name, pkg, ob, oracle, gpu):
+    p, dims, Ip, Ic, z = load_golden(name, pkg, pkg.Params)
+    m1p, m2p = pkg.compute_features(p, Ip, dims)
+    m1c, m2c, du, dv = pkg.compute_features(p, Ic, dims, planes=True)
+    assert np.array_equal(m2p, z["max2p"]) and np.array_equal(m2c, z["max2c"])
+    assert np.array_equal(m1p, z["max1p"]) and np.array_equal(m1c, z["max1c"])
+    assert oracle.fnv(np.ascontiguousarray(du[2:-2, 2:du.shape[1] - 16])) == int(z["du_interior_fnv"])
+    assert oracle.fnv(np.ascontiguousarray(dv[2:-2, 2:dv.shape[1] - 16])) == int(z["dv_interior_fnv"])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_index_findmatch_matching_golden(name, pkg, ob, oracle, gpu):
+    """a8 createIndexVector, a9 findMatch (all queries), a10 flow matching."""
+    p, dims, Ip, Ic, z = load_golden(name, pkg, pkg.Params)
+    bs, lst = pkg.create_index(p, dims, z["max2c"])
+    assert np.array_equal(bs, z["bin_start"]) and np.array_equal(lst, z["bin_list"])
+    assert np.array_equal(pkg.match_all(p, dims, z["max2c"], z["max2p"], flow=True), z["fwd"])
+    pm = pkg.match(p, dims, pkg.METHOD_FLOW, m1p=z["max2p"], m1c=z["max2c"])
+    assert pm.tobytes() == z["p_match"].tobytes()
+
+
+@pytest.mark.parametrize("case", ["kitti_1241x376", "seq_1024x284"])
+def test_known_answers_full_size(case, pkg, oracle, gpu):
+    """SURVEY Appendix-B sizes through the stateful Matcher surface (mono flow = configs[0])."""
+    z = np.load(os.path.join(GOLDEN, "known_answers.npz"))
+    W, H, blur, gain, seed, dx, dy = [int(v) for v in z[case + "__gen"]]
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    m = pkg.Matcher(pkg.Params.default())
+    assert m.pushBack(pkg.synth.frame(W, H, 0, 0, blur, gain, seed), None, dims, False)
+    assert m.pushBack(pkg.synth.frame(W, H, dx, dy, blur, gain, seed), None, dims, False)
+    m.matchFeatures(pkg.METHOD_FLOW)
+    fp, fc, pm = m.getFeatures(pkg.SET_1P), m.getFeatures(pkg.SET_1C), m.getMatches()
+    m.close()
+    assert (len(fp), len(fc), len(pm)) == (int(z[case + "__n2p"]), int(z[case + "__n2c"]), int(z[case + "__n_match"]))
+    assert oracle.fnv(fp) == int(z[case + "__fnv_max2p"]) and oracle.fnv(fc) == int(z[case + "__fnv_max2c"])
+    assert oracle.fnv(pm) == int(z[case + "__fnv_p_match"])
+    assert pm[:32].tobytes() == z[case + "__head_p_match"].tobytes()
+
+
+# ------------------------------------------------ random parameter sweep vs the oracle
+@pytest.mark.parametrize("trial", range(8))
+def test_random_configs_vs_oracle(trial, pkg, ob, oracle, gpu):
+    rng = np.random.default_rng(100 + trial)
+    W = int(rng.integers(120, 500)); H = int(rng.integers(90, 300))
+    over = {"nms_n": int(rng.integers(1, 6)), "nms_tau": int(rng.integers(5, 90)),
+            "match_binsize": int(rng.integers(10, 120)), "match_radius": int(rng.integers(5, 300)),
+            "match_disp_tolerance": int(rng.integers(0, 5)),
+            "half_resolution": int(trial % 2), "multi_stage": int((trial // 2) % 2)}
+    p, po = pkg.Params.default(**over), ob.Params.default(**over)
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    blur, gain, seed = int(rng.integers(1, 7)), int(rng.integers(1, 4)), int(rng.integers(1, 10000))
+    disp = int(rng.integers(0, 10))
+    imgs = []
+    for t in range(2):
+        dx, dy = int(rng.integers(0, 8)) * t, int(rng.integers(0, 5)) * t
+        imgs += [pkg.synth.frame(W, H, dx, dy, blur, gain, seed), pkg.synth.frame(W, H, dx + disp, dy, blur, gain, seed)]
+    for im in imgs[:2]:
+        got = pkg.compute_features(p, im, dims)
+        want = oracle.compute_features(po, im, dims)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), over
+    f = feats_for(oracle, po, dims, imgs)
+    for flow in (True, False):
+        assert np.array_equal(pkg.match_all(p, dims, f[2], f[0], flow=flow), oracle.match_all(po, dims, f[2], f[0], flow=flow)), over
+    for method in (0, 1, 2):
+        got = pkg.match(p, dims, method, *f)
+        want = oracle.matching(po, dims, method, *f)
+        assert got.tobytes() == want.tobytes(), (over, method)
+
+
+# ------------------------------------------------ stateful Matcher: ring buffer, methods
+def test_matcher_ring_buffer_and_methods(pkg, ob, oracle, gpu):
+    """pushBack ring (src/matcher.cpp:64-79), replace flag, stereo + quad + flow on one handle."""
+    W, H = 400, 200
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    p, po = pkg.Params.default(), ob.Params.default()
+    seq = pkg.synth.stereo_sequence(W, H, 4, disparity=8, blur=4, seed=21)
+    F = [[oracle.compute_features(po, im, dims)[1] for im in pair] for pair in seq]
+    m = pkg.Matcher(p)
+    m.pushBack(seq[0][0], seq[0][1], dims, False)
+    # one frame only: previous sets are empty -> no flow/quad matches, stereo works
+    m.matchFeatures(pkg.METHOD_QUAD)
+    assert len(m.getMatches()) == 0
+    m.matchFeatures(pkg.METHOD_STEREO)
+    assert m.getMatches().tobytes() == oracle.matching(po, dims, 1, m1c=F[0][0], m2c=F[0][1]).tobytes()
+    for t in (1, 2):
+        m.pushBack(seq[t][0], seq[t][1], dims, False)
+        for k, want in enumerate((F[t - 1][0], F[t - 1][1], F[t][0], F[t][1])):
+            assert np.array_equal(m.getFeatures(k), want)
+        for method in (2, 0, 1):
+            m.matchFeatures(method)
+            assert m.getMatches().tobytes() == oracle.matching(po, dims, method, F[t - 1][0], F[t - 1][1], F[t][0], F[t][1]).tobytes()
+    # replace=True overwrites the current pair and keeps the previous one
+    m.pushBack(seq[3][0], seq[3][1], dims, True)
+    assert np.array_equal(m.getFeatures(pkg.SET_1P), F[1][0]) and np.array_equal(m.getFeatures(pkg.SET_1C), F[3][0])
+    m.matchFeatures(pkg.METHOD_QUAD)
+    assert m.getMatches().tobytes() == oracle.matching(po, dims, 2, F[1][0], F[1][1], F[3][0], F[3][1]).tobytes()
+    # mono push after stereo: the right sets of the new pair are empty
+    m.pushBack(seq[0][0], None, dims, False)
+    assert len(m.getFeatures(pkg.SET_2C)) == 0 and np.array_equal(m.getFeatures(pkg.SET_1P), F[3][0])
+    m.matchFeatures(pkg.METHOD_FLOW)
+    assert m.getMatches().tobytes() == oracle.matching(po, dims, 0, m1p=F[3][0], m1c=F[0][0]).tobytes()
+    m.close()
+
+
+def test_dimension_mismatch_and_errors(pkg, gpu, capsys):
+    m = pkg.Matcher(pkg.Params.default())
+    img = np.zeros((50, 64), np.uint8)
+    assert m.pushBack(img, None, [64, 50, 32], False) is False  # bpl < width (src/matcher.cpp:59-62)
+    assert "Image dimension mismatch" in capsys.readouterr().out
+    assert m.pushBack(img, None, [0, 50, 64], False) is False
+    with pytest.raises(pkg.VisoHipError) as e:
+        m.matchFeatures(0)  # nothing pushed yet
+    assert e.value.code == pkg.VH_ERR_STATE
+    with pytest.raises(pkg.VisoHipError):
+        m.matchFeatures(7)
+    m.close()
+
+
+def test_tiny_and_empty_inputs(pkg, ob, oracle, gpu):
+    p, po = pkg.Params.default(), ob.Params.default()
+    # image too small for a single NMS block, and a flat image: no features, no crash
+    for W, H, fill in ((16, 16, 0), (18, 40, 0), (200, 100, 77)):
+        img = np.full((H, pkg.synth.bytes_per_line(W)), fill, np.uint8)
+        a = pkg.compute_features(p, img, [W, H, img.shape[1]])
+        assert len(a[0]) == 0 and len(a[1]) == 0
+    dims = [200, 100, 208]
+    f = oracle.compute_features(po, pkg.synth.frame(200, 100, blur=3, seed=2), dims)[1]
+    empty = np.zeros((0, 12), np.int32)
+    # empty candidate set: findMatch returns min_ind = 0 for every query (src/matcher.cpp:221)
+    assert np.array_equal(pkg.match_all(p, dims, f, empty), np.zeros(len(f), np.int32))
+    assert len(pkg.match_all(p, dims, empty, f)) == 0
+    for method in (0, 1, 2):
+        assert len(pkg.match(p, dims, method, m1p=empty, m2p=f, m1c=f, m2c=empty)) == 0
+    # a single feature on both sides closes its own circle
+    one = f[:1]
+    assert pkg.match(p, dims, 0, m1p=one, m1c=one).tobytes() == oracle.matching(po, dims, 0, m1p=one, m1c=one).tobytes()
+    # queries whose window holds no candidate fall back to index 0 and must not close a circle by accident
+    far = f.copy(); far[:, 0] = np.minimum(far[:, 0], 30)
+    got = pkg.match_all(pkg.Params.default(match_radius=3), dims, f, far)
+    assert np.array_equal(got, oracle.match_all(ob.Params.default(match_radius=3), dims, f, far))
+
+
+def test_pixel_dedup_mask(pkg, ob, oracle, gpu):
+    """The fork's first-writer-per-pixel mask M (src/matcher.cpp:331-334): two
+    current features on the same pixel (different classes) that both close."""
+    dims = [300, 200, 304]
+    p, po = pkg.Params.default(), ob.Params.default()
+    rng = np.random.default_rng(5)
+    n = 400
+    prev = np.zeros((n, 12), np.int32)
+    prev[:, 0] = rng.integers(10, 290, n); prev[:, 1] = rng.integers(10, 190, n)
+    prev[:, 3] = rng.integers(0, 4, n)
+    prev[:, 4:] = rng.integers(0, 2**31 - 1, (n, 8))
+    cur = prev.copy()
+    # force pixel collisions: pairs (2k, 2k+1) share a pixel; classes differ so both can match
+    cur[1::2, 0:2] = cur[0::2, 0:2]
+    prev[1::2, 0:2] = prev[0::2, 0:2]
+    prev[0::2, 3] = 0; cur[0::2, 3] = 0; prev[1::2, 3] = 1; cur[1::2, 3] = 1
+    want = oracle.matching(po, dims, 0, m1p=prev, m1c=cur)
+    got = pkg.match(p, dims, 0, m1p=prev, m1c=cur)
+    assert 0 < len(want) < n and got.tobytes() == want.tobytes()
+
+
+def test_tie_breaking_order(pkg, ob, oracle, gpu):
+    """Identical descriptors everywhere: the winner is decided purely by the
+    reference's visiting order (u_bin, v_bin, list position; src/matcher.cpp:243-267)."""
+    dims = [640, 480, 640]
+    rng = np.random.default_rng(11)
+    n = 3000
+    a = np.zeros((n, 12), np.int32)
+    a[:, 0] = rng.integers(0, 640, n); a[:, 1] = rng.integers(0, 480, n); a[:, 3] = rng.integers(0, 4, n)
+    a[:, 4:] = 0x40404040
+    b = a.copy(); rng.shuffle(b, axis=0)
+    for bs, r in ((50, 200), (33, 77), (100, 40)):
+        p, po = pkg.Params.default(match_binsize=bs, match_radius=r), ob.Params.default(match_binsize=bs, match_radius=r)
+        for flow in (True, False):
+            assert np.array_equal(pkg.match_all(p, dims, a, b, flow=flow), oracle.match_all(po, dims, a, b, flow=flow))
+        assert pkg.match(p, dims, 2, a, b, b, a).tobytes() == oracle.matching(po, dims, 2, a, b, b, a).tobytes()
+
+
+def test_capacity_errors(pkg, gpu):
+    W, H = 320, 160
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    img = pkg.synth.frame(W, H, blur=4, seed=3)
+    m = pkg.Matcher(pkg.Params.default(), max_features=100, max_matches=50)
+    m.pushBack(img, None, dims, False)
+    n = C.c_int32(0)
+    buf = np.zeros((100, 12), np.int32)
+    rc = pkg._lib().vh_get_features(m._h, pkg.SET_1C, buf.ctypes.data_as(C.c_void_p), 100, C.byref(n))
+    assert rc == pkg.VH_ERR_CAPACITY and n.value > 100  # true count is still reported
+    m.close()
+    full = pkg.compute_features(pkg.Params.default(), img, dims)[1]
+    assert np.array_equal(buf, full[:100])  # the first `capacity` records are exact
+
+
+def test_bucket_features(pkg, ob, oracle, gpu):
+    """f-2: Matcher::bucketFeatures incl. the LFSR shuffle (src/matcher.cpp:113-187)."""
+    g = np.load(os.path.join(GOLDEN, "bucket_1024x284.npz"))
+    dims = [1024, 284, 1024]
+    for key in g.files:
+        _, mf, bw, bh = key.split("_")
+        m = pkg.Matcher(pkg.Params.default())
+        m.pushBack(pkg.synth.frame(1024, 284, 0, 0), None, dims, False)
+        m.pushBack(pkg.synth.frame(1024, 284, 5, 1), None, dims, False)
+        m.matchFeatures(pkg.METHOD_FLOW)
+        m.bucketFeatures(int(mf), float(bw), float(bh))
+        assert m.getMatches().tobytes() == g[key].tobytes(), key
+        m.close()
+    # beyond the reference's fixed bucket array (1241x376 needs 200 buckets): vs the oracle
+    po = ob.Params.default()
+    d2 = [1241, 376, 1248]
+    fp = oracle.compute_features(po, pkg.synth.frame(1241, 376, 0, 0), d2)[1]
+    fc = oracle.compute_features(po, pkg.synth.frame(1241, 376, 5, 1), d2)[1]
+    want = oracle.bucket_features(oracle.matching(po, d2, 0, m1p=fp, m1c=fc), 2, 50, 50)
+    m = pkg.Matcher(pkg.Params.default())
+    m.pushBack(pkg.synth.frame(1241, 376, 0, 0), None, d2, False)
+    m.pushBack(pkg.synth.frame(1241, 376, 5, 1), None, d2, False)
+    m.matchFeatures(0); m.bucketFeatures(2, 50, 50)
+    assert m.getMatches().tobytes() == want.tobytes()
+    m.close()
+
+
+# ------------------------------------------------ multi-stream group
+def test_stream_group_equals_independent_matchers(pkg, ob, oracle, gpu):
+    """configs[3] in miniature: S independent sequences stepped together give,
+    stream by stream, exactly what one Matcher per sequence gives."""
+    S, W, H = 5, 360, 180
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    po = ob.Params.default()
+    seqs = [pkg.synth.stereo_sequence(W, H, 3, disparity=5 + s, blur=3 + s % 3, seed=40 + s) for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    for t in range(3):
+        L = np.stack([seqs[s][t][0] for s in range(S)]); R = np.stack([seqs[s][t][1] for s in range(S)])
+        g.pushBack(L, R, dims, False)
+        if t == 0:
+            continue
+        for method in (2, 0, 1):
+            g.matchFeatures(method)
+            nf, nm = g.getCounts()
+            for s in range(S):
+                f = feats_for(oracle, po, dims, (seqs[s][t - 1][0], seqs[s][t - 1][1], seqs[s][t][0], seqs[s][t][1]))
+                assert [len(x) for x in f] == list(nf[s])
+                for k in range(4):
+                    assert np.array_equal(g.getFeatures(s, k), f[k])
+                want = oracle.matching(po, dims, method, *f)
+                assert nm[s] == len(want) and g.getMatches(s).tobytes() == want.tobytes()
+    g.close()
+
+
+# ------------------------------------------------ full-size configs: exact where the oracle is fast, properties beyond
+def test_kitti_stereo_quad_full_size(pkg, ob, oracle, gpu):
+    """configs[1]: KITTI 1241x376 stereo quad-match, default parameters."""
+    W, H = 1241, 376
+    dims = [W, H, 1248]
+    po = ob.Params.default()
+    seq = pkg.synth.stereo_sequence(W, H, 2, disparity=12)
+    m = pkg.Matcher(pkg.Params.default())
+    for l, r in seq:
+        m.pushBack(l, r, dims, False)
+    m.matchFeatures(pkg.METHOD_QUAD)
+    got = m.getMatches()
+    f = [m.getFeatures(k) for k in range(4)]
+    m.close()
+    want_f = feats_for(oracle, po, dims, (seq[0][0], seq[0][1], seq[1][0], seq[1][1]))
+    for a, b in zip(f, want_f):
+        assert np.array_equal(a, b)
+    want = oracle.matching(po, dims, 2, *want_f)
+    assert len(want) > 5000 and got.tobytes() == want.tobytes()
+    ok = (got["u1p"] - got["u2p"] == 12) & (got["u1c"] - got["u2c"] == 12) & (got["u1p"] - got["u1c"] == 5) & (got["v1p"] - got["v1c"] == 1)
+    assert ok.mean() > 0.95  # the generator's ground truth
+
+
+def _check_match_properties(pkg, oracle, po, dims, f, got, method, rng, nsample):
+    """Size-independent checks: emission order, sign constraints, circle
+    closure re-derived with the oracle's findMatch on a sample of matches."""
+    drive = "i1p" if method == 2 else "i1c"
+    assert np.all(np.diff(got[drive]) > 0)
+    if method == 2:
+        assert np.all(got["u1p"] >= got["u2p"]) and np.all(got["u1c"] >= got["u2c"])
+    idx = rng.choice(len(got), size=min(nsample, len(got)), replace=False)
+    ubn = -(-dims[0] // po.match_binsize); vbn = -(-dims[1] // po.match_binsize)
+    index = [oracle.create_index(po, x, dims) for x in f]
+    fm = oracle.lib.vo_find_match
+    fm.restype = C.c_int32
+
+    def find(a, i, b, flow):
+        bs, lst = index[b]
+        return fm(C.byref(po), f[a].ctypes.data_as(C.c_void_p), int(i), f[b].ctypes.data_as(C.c_void_p),
+                  bs.ctypes.data_as(C.c_void_p), lst.ctypes.data_as(C.c_void_p), ubn, vbn, int(flow), -1.0, -1.0)
+    for k in idx:
+        r = got[k]
+        if method == 2:
+            assert find(0, r["i1p"], 1, 0) == r["i2p"] and find(1, r["i2p"], 3, 1) == r["i2c"]
+            assert find(3, r["i2c"], 2, 0) == r["i1c"] and find(2, r["i1c"], 0, 1) == r["i1p"]
+        else:
+            assert find(2, r["i1c"], 0, 1) == r["i1p"] and find(0, r["i1p"], 2, 1) == r["i1c"]
+        for tag, s in (("1p", 0), ("2p", 1), ("1c", 2), ("2c", 3)):
+            i = r["i" + tag]
+            if i >= 0:
+                assert r["u" + tag] == f[s][i, 0] and r["v" + tag] == f[s][i, 1]
+
+
+def test_1080p_all_classes_radius200(pkg, ob, oracle, gpu):
+    """configs[2]: 1920x1080 stereo, half_resolution=0, match_radius=200."""
+    W, H = 1920, 1080
+    dims = [W, H, 1920]
+    po = ob.Params.default()
+    seq = pkg.synth.stereo_sequence(W, H, 2, disparity=10, seed=2)
+    m = pkg.Matcher(pkg.Params.default())
+    for l, r in seq:
+        m.pushBack(l, r, dims, False)
+    m.matchFeatures(pkg.METHOD_QUAD)
+    got = m.getMatches()
+    f = [m.getFeatures(k) for k in range(4)]
+    m.close()
+    want_f = feats_for(oracle, po, dims, (seq[0][0], seq[0][1], seq[1][0], seq[1][1]))
+    for a, b in zip(f, want_f):
+        assert np.array_equal(a, b)
+    assert min(len(x) for x in f) > 30000 and len(got) > 20000
+    assert set(np.unique(f[2][:, 3])) == {0, 1, 2, 3}
+    _check_match_properties(pkg, oracle, po, dims, f, got, 2, np.random.default_rng(1), 300)
+    # exact table check for one whole pass (the oracle needs ~1 s for it)
+    assert np.array_equal(pkg.match_all(pkg.Params.default(), dims, f[2], f[3], flow=False),
+                          oracle.match_all(po, dims, f[2], f[3], flow=False))
+
+
+def test_4k_dense_small_bins(pkg, ob, oracle, gpu):
+    """configs[4]: 3840x2160, nms_n=3, match_binsize=25 (53 592 bins)."""
+    W, H = 3840, 2160
+    dims = [W, H, 3840]
+    over = {"nms_n": 3, "match_binsize": 25}
+    p, po = pkg.Params.default(**over), ob.Params.default(**over)
+    Ip = pkg.synth.frame(W, H, 0, 0, seed=3); Ic = pkg.synth.frame(W, H, 5, 1, seed=3)
+    m = pkg.Matcher(p)
+    m.pushBack(Ip, None, dims, False)
+    m.pushBack(Ic, None, dims, False)
+    m.matchFeatures(pkg.METHOD_FLOW)
+    got = m.getMatches()
+    fp, fc = m.getFeatures(pkg.SET_1P), m.getFeatures(pkg.SET_1C)
+    m.close()
+    assert np.array_equal(fp, oracle.compute_features(po, Ip, dims)[1])
+    assert np.array_equal(fc, oracle.compute_features(po, Ic, dims)[1])
+    assert len(fc) > 100000 and len(got) > 80000
+    f = [fp, np.zeros((0, 12), np.int32), fc, np.zeros((0, 12), np.int32)]
+    _check_match_properties(pkg, oracle, po, dims, f, got, 0, np.random.default_rng(2), 200)
+    assert np.mean((got["u1p"] - got["u1c"] == 5) & (got["v1p"] - got["v1c"] == 1)) > 0.9
+    # no pixel of the current image is matched twice (mask M)
+    pix = got["v1c"].astype(np.int64) * W + got["u1c"].astype(np.int64)
+    assert len(np.unique(pix)) == len(pix)
+    bs, lst = pkg.create_index(p, dims, fc)
+    bo, lo = oracle.create_index(po, fc, dims)
+    assert len(bs) == 4 * 154 * 87 + 1 and np.array_equal(bs, bo) and np.array_equal(lst, lo)
