@@ -33,7 +33,7 @@ METRIC = "stereo frame-pairs/sec (detect+match), KITTI 1241x376; matches bit-exa
 W, H = 1241, 376
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNELS = ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill", "bin_sort",
-           "match", "chain", "emit_matches")
+           "match_stereo", "match_flow", "chain", "emit_matches")
 
 
 def make_frames(pkg, n_streams: int, n_frames: int, rank: int):

@@ -135,7 +135,7 @@ struct Group {
     if (rc != VH_OK) return rc;
     dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
     int64_t c = req_features > 0 ? req_features : std::max<int64_t>(4 * (int64_t)g.nblocks, 64);
-    if (c > (1 << 20) - 1) c = (1 << 20) - 1;
+    if (c > (1 << 19) - 1) c = (1 << 19) - 1;  // match keys carry a 19-bit position
     cap = (int32_t)c;
     mcap = req_matches > 0 ? req_matches : cap;
 
@@ -157,6 +157,12 @@ struct Group {
     if ((rc = dmalloc(&sets.cursor, ns * sets.nbins, true))) return rc;
     if ((rc = dmalloc(&sets.tmp_idx, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.count, ns, true))) return rc;
+    const size_t nrow = 4 * (size_t)dims[1];
+    if ((rc = dmalloc(&sets.row_start, ns * (nrow + 1), true))) return rc;
+    if ((rc = dmalloc(&sets.row_hist, ns * nrow, true))) return rc;
+    if ((rc = dmalloc(&sets.row_cursor, ns * nrow, true))) return rc;
+    if ((rc = dmalloc(&sets.r_meta, ns * cap, false))) return rc;
+    if ((rc = dmalloc(&sets.r_desc, ns * cap * 8, false))) return rc;
     if ((rc = dmalloc(&sets.tiles, ns * sets.max_tiles, false))) return rc;
     if ((rc = dmalloc(&sets.tile_cnt, ns, true))) return rc;
     if ((rc = dmalloc(&d_rec, 2 * (size_t)S * std::max(g.nblocks, 1), false))) return rc;
@@ -200,6 +206,9 @@ struct Group {
     if (zero_first) {
       VH_HIP(hipMemsetAsync(sets.hist + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
       VH_HIP(hipMemsetAsync(sets.cursor + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
+      const size_t nrow = 4 * (size_t)dims[1];
+      VH_HIP(hipMemsetAsync(sets.row_hist + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
+      VH_HIP(hipMemsetAsync(sets.row_cursor + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
     }
     { Scope sc(this, "bin_hist"); vh_launch_bin_hist(sets, set0, nsets, stream); }
     { Scope sc(this, "bin_scan"); vh_launch_bin_scan(sets, set0, nsets, stream); }
@@ -261,13 +270,13 @@ struct Group {
     VhMatchArgs a{};
     a.S = S; a.pair_cur = pair_cur; a.radius = p.match_radius; a.disp_tol = p.match_disp_tolerance;
     if (method == VH_METHOD_FLOW) {  // matcher.cpp:320-321
-      a.npass = 2; a.pass[0] = {VH_SET_1C, VH_SET_1P, 1}; a.pass[1] = {VH_SET_1P, VH_SET_1C, 1};
+      a.npass = 2; a.pass[0] = {VH_SET_1C, VH_SET_1P, 1, 0}; a.pass[1] = {VH_SET_1P, VH_SET_1C, 1, 1};
     } else if (method == VH_METHOD_STEREO) {
-      a.npass = 2; a.pass[0] = {VH_SET_1C, VH_SET_2C, 0}; a.pass[1] = {VH_SET_2C, VH_SET_1C, 0};
+      a.npass = 2; a.pass[0] = {VH_SET_1C, VH_SET_2C, 0, 0}; a.pass[1] = {VH_SET_2C, VH_SET_1C, 0, 1};
     } else {
       a.npass = 4;
-      a.pass[0] = {VH_SET_1P, VH_SET_2P, 0}; a.pass[1] = {VH_SET_2P, VH_SET_2C, 1};
-      a.pass[2] = {VH_SET_2C, VH_SET_1C, 0}; a.pass[3] = {VH_SET_1C, VH_SET_1P, 1};
+      a.pass[0] = {VH_SET_1P, VH_SET_2P, 0, 0}; a.pass[1] = {VH_SET_2P, VH_SET_2C, 1, 1};
+      a.pass[2] = {VH_SET_2C, VH_SET_1C, 0, 2}; a.pass[3] = {VH_SET_1C, VH_SET_1P, 1, 3};
     }
     return a;
   }
@@ -283,7 +292,8 @@ struct Group {
         epoch = 1;
       }
     }
-    { Scope sc(this, "match"); vh_launch_match(sets, a, d_best, stream); }
+    { Scope sc(this, "match_stereo"); vh_launch_match_stereo(sets, a, d_best, stream); }
+    { Scope sc(this, "match_flow"); vh_launch_match_flow(sets, a, d_best, stream); }
     { Scope sc(this, "chain"); vh_launch_chain(sets, a, method, d_best, d_chain, d_mask, epoch, stream); }
     { Scope sc(this, "emit_matches"); vh_launch_emit_matches(sets, a, method, d_chain, d_mask, epoch, d_matches, mcap, d_match_count, stream); }
     VH_HIP(hipGetLastError());
@@ -706,8 +716,9 @@ int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3], 
   if ((rc = gq->load_features(VH_SET_1C, m1, n1))) return rc;
   if ((rc = gq->load_features(VH_SET_1P, m2, n2))) return rc;
   VhMatchArgs a = gq->match_args(VH_METHOD_FLOW);
-  a.npass = 1; a.pass[0] = {VH_SET_1C, VH_SET_1P, flow ? 1 : 0};
-  vh_launch_match(gq->sets, a, gq->d_best, gq->stream);
+  a.npass = 1; a.pass[0] = {VH_SET_1C, VH_SET_1P, flow ? 1 : 0, 0};
+  vh_launch_match_stereo(gq->sets, a, gq->d_best, gq->stream);
+  vh_launch_match_flow(gq->sets, a, gq->d_best, gq->stream);
   VH_HIP(hipGetLastError());
   if (n1) VH_HIP(hipMemcpyAsync(best, gq->d_best, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, gq->stream));
   VH_HIP(hipStreamSynchronize(gq->stream));

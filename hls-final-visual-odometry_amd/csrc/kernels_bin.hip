@@ -31,8 +31,9 @@ __global__ void bin_hist_kernel(VhSets s, int32_t set0) {
   const int32_t n = min(s.count[set], s.cap);
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int32_t b = feature_bin(s.feat + ((int64_t)set * s.cap + i) * 12, s);
-  atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
+  const int32_t *f = s.feat + ((int64_t)set * s.cap + i) * 12;
+  atomicAdd(&s.hist[(int64_t)set * s.nbins + feature_bin(f, s)], 1);
+  atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + f[3] * s.H + f[1]], 1);
 }
 
 // One workgroup per set: exclusive scan of the histogram into bin_start, and
@@ -93,6 +94,32 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
     __syncthreads();
   }
   if (tid == 0) s.tile_cnt[set] = min(sCarry, s.max_tiles);
+  __syncthreads();
+
+  // row index: exclusive scan of the (class, v) histogram
+  const int32_t nrow = 4 * s.H;
+  const int32_t *__restrict__ rh = s.row_hist + (int64_t)set * nrow;
+  int32_t *__restrict__ rs = s.row_start + (int64_t)set * (nrow + 1);
+  if (tid == 0) sCarry = 0;
+  __syncthreads();
+  for (int32_t b0 = 0; b0 < nrow; b0 += 1024) {
+    const int32_t b = b0 + tid;
+    const int32_t v = (b < nrow) ? rh[b] : 0;
+    sPart[tid] = v;
+    __syncthreads();
+    for (int32_t d = 1; d < 1024; d <<= 1) {
+      const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
+      __syncthreads();
+      sPart[tid] += t;
+      __syncthreads();
+    }
+    const int32_t incl = sPart[tid], carry = sCarry;
+    if (b < nrow) rs[b] = carry + incl - v;
+    __syncthreads();
+    if (tid == 1023) sCarry = carry + incl;
+    __syncthreads();
+  }
+  if (tid == 0) rs[nrow] = sCarry;
 }
 
 __global__ void bin_fill_kernel(VhSets s, int32_t set0) {
@@ -120,6 +147,11 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0) {
   int32_t *__restrict__ sidx = s.s_idx + (int64_t)set * s.cap;
   uint32_t *__restrict__ suv = s.s_uv + (int64_t)set * s.cap;
   uint4 *__restrict__ sdesc = (uint4 *)(s.s_desc + (int64_t)set * s.cap * 8);
+  const int32_t nrow = 4 * s.H;
+  const int32_t *__restrict__ rs = s.row_start + (int64_t)set * (nrow + 1);
+  int32_t *__restrict__ rcur = s.row_cursor + (int64_t)set * nrow;
+  uint2 *__restrict__ rmeta = s.r_meta + (int64_t)set * s.cap;
+  uint4 *__restrict__ rdesc = (uint4 *)(s.r_desc + (int64_t)set * s.cap * 8);
   for (int32_t e0 = 0; e0 < L; e0 += 64) {
     const int32_t e = e0 + lane;
     const int32_t mine = (e < L) ? tmp[p0 + e] : 0x7FFFFFFF;
@@ -137,6 +169,13 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0) {
       suv[p] = (uint32_t)h.x | ((uint32_t)h.y << 16);
       sdesc[2 * (int64_t)p] = d0;
       sdesc[2 * (int64_t)p + 1] = d1;
+      // row-ordered copy for the stereo search; order inside a row is
+      // irrelevant (the matcher minimises a (cost, bin position) key)
+      const int32_t row = (int32_t)h.w * s.H + (int32_t)h.y;
+      const int32_t rp = rs[row] + atomicAdd(&rcur[row], 1);
+      rmeta[rp] = make_uint2(h.x, (uint32_t)p);
+      rdesc[2 * (int64_t)rp] = d0;
+      rdesc[2 * (int64_t)rp + 1] = d1;
     }
   }
 }

@@ -22,6 +22,10 @@
 //    bin range.
 #include "vh_dev.h"
 
+#ifndef VH_SB
+#define VH_SB 4
+#endif
+
 namespace {
 
 __device__ __forceinline__ int32_t wave_min(int32_t v) {
@@ -34,6 +38,10 @@ __device__ __forceinline__ int32_t wave_max(int32_t v) {
   for (int32_t d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
   return v;
 }
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t x) { return __builtin_bit_cast(us2, x); }
+__device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
 
 __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) {
   return __builtin_amdgcn_sad_u8(a, b, acc);  // v_sad_u8: 4 byte-wise |a-b| summed into acc
@@ -78,32 +86,113 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   const int32_t VB0 = __builtin_amdgcn_readfirstlane(wave_min(vb_lo));
   const int32_t VB1 = __builtin_amdgcn_readfirstlane(wave_max(vb_hi));
 
-  uint32_t best_cost = 0x7FFFFFFFu;  // reference: min_cost = 10000000 > any SAD (<= 8160)
-  int32_t best_pos = -1;
+  // Accept test of matcher.cpp:249 in packed 16-bit arithmetic: with
+  // t = (u2,v2) - (u_lo,v_lo) (mod 2^16 per half), the candidate is inside the
+  // window iff t.u <= 2*radius and t.v <= 2*rv, i.e. iff min(t, span) == t.
+  // Exact because coordinates are < 2^14 and radii <= 2^14 (|u2-u1|+r < 2^15).
+  const us2 lo2 = {(unsigned short)u_lo, (unsigned short)v_lo};
+  const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * rv)};
+  // best = min over accepted candidates of (SAD << 19 | position): positions in
+  // bin order are the reference's visiting order, so this key reproduces its
+  // strict-< first-minimum rule (matcher.cpp:264).  SAD <= 8160 < 2^13.
+  uint32_t best_key = 0xFFFFFFFFu;
+  auto consider = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) {
+    const us2 t = as_us2(uv2) - lo2;
+    const us2 m = __builtin_elementwise_min(t, span2);
+    const bool out = as_u32(t) != as_u32(m);
+    uint32_t sad = sad4(a0.x, b0.x, 0);
+    sad = sad4(a0.y, b0.y, sad);
+    sad = sad4(a0.z, b0.z, sad);
+    sad = sad4(a0.w, b0.w, sad);
+    sad = sad4(a1.x, b1.x, sad);
+    sad = sad4(a1.y, b1.y, sad);
+    sad = sad4(a1.z, b1.z, sad);
+    sad = sad4(a1.w, b1.w, sad);
+    const uint32_t key = out ? 0xFFFFFFFFu : ((sad << 19) | (uint32_t)p);
+    best_key = min(best_key, key);
+  };
   for (int32_t ub = UB0; ub <= UB1; ub++) {
     const int32_t row = (c * s.ubn + ub) * s.vbn;
     const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
     const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + VB1 + 1]);
-    for (int32_t p = p0; p < p1; p++) {
-      const uint32_t uv2 = cuv[p];
-      const uint4 b0 = cdesc[2 * (int64_t)p], b1 = cdesc[2 * (int64_t)p + 1];
-      const int32_t u2 = uv2 & 0xFFFF, v2 = uv2 >> 16;
-      const bool in = (u2 >= u_lo) & (u2 <= u_hi) & (v2 >= v_lo) & (v2 <= v_hi);  // matcher.cpp:249
-      uint32_t sad = sad4(a0.x, b0.x, 0);
-      sad = sad4(a0.y, b0.y, sad);
-      sad = sad4(a0.z, b0.z, sad);
-      sad = sad4(a0.w, b0.w, sad);
-      sad = sad4(a1.x, b1.x, sad);
-      sad = sad4(a1.y, b1.y, sad);
-      sad = sad4(a1.z, b1.z, sad);
-      sad = sad4(a1.w, b1.w, sad);
-      if (in && sad < best_cost) { best_cost = sad; best_pos = p; }  // strict <: first minimum wins
+    int32_t p = p0;
+    // 4 candidates per trip: the scalar record loads are issued back to back so
+    // that one scalar-cache round trip is paid per 4 candidates, not per candidate
+    for (; p + 4 <= p1; p += 4) {
+      const uint32_t w0 = cuv[p], w1 = cuv[p + 1], w2 = cuv[p + 2], w3 = cuv[p + 3];
+      const uint4 c00 = cdesc[2 * (int64_t)p + 0], c01 = cdesc[2 * (int64_t)p + 1];
+      const uint4 c10 = cdesc[2 * (int64_t)p + 2], c11 = cdesc[2 * (int64_t)p + 3];
+      const uint4 c20 = cdesc[2 * (int64_t)p + 4], c21 = cdesc[2 * (int64_t)p + 5];
+      const uint4 c30 = cdesc[2 * (int64_t)p + 6], c31 = cdesc[2 * (int64_t)p + 7];
+      consider(w0, c00, c01, p);
+      consider(w1, c10, c11, p + 1);
+      consider(w2, c20, c21, p + 2);
+      consider(w3, c30, c31, p + 3);
     }
+    for (; p < p1; p++) consider(cuv[p], cdesc[2 * (int64_t)p], cdesc[2 * (int64_t)p + 1], p);
   }
+  const int32_t best_pos = (best_key == 0xFFFFFFFFu) ? -1 : (int32_t)(best_key & 0x7FFFFu);
   if (valid) {
     // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
     const int32_t r = (best_pos >= 0) ? cidx[best_pos] : 0;
-    best[((int64_t)stream * 4 + pass) * s.cap + qidx[q]] = r;
+    best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q]] = r;
+  }
+}
+
+// -------------------------------------------------------------- match (stereo)
+// The 1-d stereo search (v window of +-match_disp_tolerance, stock libviso2;
+// SURVEY App. A.7) accepts only a few dozen candidates per query, all within a
+// handful of image rows, so walking whole 50x50 bins would waste >95 % of the
+// work.  Here each lane walks its OWN candidates: the (class, v) row index makes
+// rows v1-tol..v1+tol one contiguous range, the lane tests |u2-u1| <= radius
+// and reduces with the same (SAD<<19 | bin position) key, which makes the
+// visiting order irrelevant -- the result equals findMatch's first minimum in
+// (u_bin, v_bin, list) order.
+__global__ void __launch_bounds__(256)
+match_stereo_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
+  // 16 lanes per query: the lanes of a group take consecutive candidates of the
+  // query's row range, so a group's loads are contiguous (a per-lane walk would
+  // gather 64 unrelated cache lines per load instruction), then min-reduce the key.
+  const int32_t pass = blockIdx.y, stream = blockIdx.z;
+  const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
+  const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
+  const int32_t nq = min(s.count[qset], s.cap);
+  const int32_t q = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const bool live = q < nq;
+  const int32_t ql = live ? q : 0;
+  const int32_t orig = s.s_idx[(int64_t)qset * s.cap + ql];
+  const uint32_t uv1 = s.s_uv[(int64_t)qset * s.cap + ql];
+  const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
+  const uint4 a0 = qdesc[2 * (int64_t)ql], a1 = qdesc[2 * (int64_t)ql + 1];
+  const int32_t c = s.feat[((int64_t)qset * s.cap + orig) * 12 + 3];
+  const int32_t u1 = uv1 & 0xFFFF, v1 = uv1 >> 16;
+  const int32_t v_lo = max(v1 - a.disp_tol, 0), v_hi = min(v1 + a.disp_tol, s.H - 1);
+  const int32_t *__restrict__ crs = s.row_start + (int64_t)cset * (4 * s.H + 1) + c * s.H;
+  const uint2 *__restrict__ rmeta = s.r_meta + (int64_t)cset * s.cap;
+  const uint4 *__restrict__ rdesc = (const uint4 *)(s.r_desc + (int64_t)cset * s.cap * 8);
+  const int32_t r0 = live ? crs[v_lo] : 0, r1 = live ? crs[v_hi + 1] : 0;
+  uint32_t best_key = 0xFFFFFFFFu;
+  for (int32_t r = r0 + sub; r < r1; r += 16) {
+    const uint2 meta = rmeta[r];
+    const uint4 b0 = rdesc[2 * (int64_t)r], b1 = rdesc[2 * (int64_t)r + 1];
+    const int32_t du = (int32_t)meta.x - u1;
+    const bool in = (du >= -a.radius) & (du <= a.radius);  // matcher.cpp:249 (v holds by construction)
+    uint32_t sad = sad4(a0.x, b0.x, 0);
+    sad = sad4(a0.y, b0.y, sad);
+    sad = sad4(a0.z, b0.z, sad);
+    sad = sad4(a0.w, b0.w, sad);
+    sad = sad4(a1.x, b1.x, sad);
+    sad = sad4(a1.y, b1.y, sad);
+    sad = sad4(a1.z, b1.z, sad);
+    sad = sad4(a1.w, b1.w, sad);
+    best_key = min(best_key, in ? ((sad << 19) | meta.y) : 0xFFFFFFFFu);
+  }
+#pragma unroll
+  for (int32_t d = 8; d >= 1; d >>= 1) best_key = min(best_key, (uint32_t)__shfl_xor((int32_t)best_key, d));
+  if (live && sub == 0) {
+    // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
+    const int32_t res = (best_key == 0xFFFFFFFFu) ? 0 : s.s_idx[(int64_t)cset * s.cap + (best_key & 0x7FFFFu)];
+    best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + orig] = res;
   }
 }
 
@@ -239,9 +328,26 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
 
 }  // namespace
 
-void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
-  dim3 grid((s.max_tiles + 3) / 4, a.npass, a.S);
-  hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, st, s, a, best);
+// The passes are split by search type: 2-d flow search (wave-uniform candidate
+// stream over bins) and 1-d stereo search (per-lane rows).
+static VhMatchArgs filter_passes(const VhMatchArgs &a, int32_t flow) {
+  VhMatchArgs r = a;
+  r.npass = 0;
+  for (int32_t k = 0; k < a.npass; k++)
+    if ((a.pass[k].flow != 0) == (flow != 0)) r.pass[r.npass++] = a.pass[k];
+  return r;
+}
+void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
+  const VhMatchArgs sr = filter_passes(a, 0);
+  if (!sr.npass) return;
+  dim3 grid((s.cap + 15) / 16, sr.npass, a.S);  // 16 queries per workgroup
+  hipLaunchKernelGGL(match_stereo_kernel, grid, dim3(256), 0, st, s, sr, best);
+}
+void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
+  const VhMatchArgs fl = filter_passes(a, 1);
+  if (!fl.npass) return;
+  dim3 grid((s.max_tiles + 3) / 4, fl.npass, a.S);
+  hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, st, s, fl, best);
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, hipStream_t st) {

@@ -17,6 +17,11 @@
 //   bin_start [set][nbins+1] int32   CSR over bins, bin = (c*ubn+ub)*vbn+vb
 //                                    (u-bin major: the iteration order of
 //                                    Matcher::findMatch, src/matcher.cpp:243-246)
+//   row_start [set][4*H+1]   int32   CSR over (class, v) rows: the stereo search
+//                                    (v window of +-disp_tolerance) walks one
+//                                    contiguous row range per query
+//   r_meta    [set][cap]     uint2   {u, bin-order position} in row order
+//   r_desc    [set][cap][8]  uint32  descriptor in row order
 //   rec       [image][nblocks] u64   per NMS block 4 x u16 position codes
 //   best      [stream][pass][cap] int32  findMatch result for every query
 //   matches   [stream][mcap] p_match (48 B, src/matcher.h:89-104)
@@ -54,6 +59,12 @@ struct VhSets {
   int32_t *cursor;
   int32_t *tmp_idx;
   int32_t *count;
+  // row index (stereo search): the same records ordered by (class, v)
+  int32_t *row_start;  // [set][4*H+1]
+  int32_t *row_hist;   // [set][4*H]
+  int32_t *row_cursor; // [set][4*H]
+  uint2 *r_meta;       // [set][cap] {u, position in bin order}
+  uint32_t *r_desc;    // [set][cap][8]
   int4 *tiles;       // [set][max_tiles] {q0, q1, class, ub}
   int32_t *tile_cnt; // [set]
   int32_t cap, nbins, ubn, vbn, binsize, max_tiles;
@@ -64,6 +75,7 @@ struct VhPass {
   int32_t qset;  // role (VH_SET_*) providing the queries
   int32_t cset;  // role providing the candidates
   int32_t flow;  // 1: +-radius in v; 0: +-disp_tolerance (stereo search)
+  int32_t slot;  // which of the 4 result tables of the stream receives this pass
 };
 
 struct VhMatchArgs {
@@ -116,7 +128,8 @@ void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, hipStream_
 void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, int32_t *list_ref,
                          hipStream_t st);
 
-void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
+void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
+void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, hipStream_t st);
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
