@@ -120,7 +120,7 @@ struct Group {
       g.FW = g.tbx * (g.n + 1) + 2 * g.n; g.FH = g.tby * (g.n + 1) + 2 * g.n;
       g.IW = g.FW + 4; g.IH = g.FH + 4;
       g.IWp = round_up(g.IW, 4); g.FWp = g.FW;
-      const size_t lds = (size_t)g.IH * g.IWp + 4 * (size_t)g.FH * g.FWp;
+      const size_t lds = (size_t)g.IH * g.IWp + 4 * (size_t)g.FH * g.FWp + 4 + 24 * (size_t)g.tbx * g.tby;
       if (lds <= 60 * 1024) return VH_OK;
     }
     return VH_ERR_UNSUPPORTED;

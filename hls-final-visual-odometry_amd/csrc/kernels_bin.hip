@@ -12,6 +12,7 @@
 // Matcher::findMatch visits candidates (src/matcher.cpp:243-246) is simply
 // ascending position -- the first-minimum tie-break becomes "lowest position".
 #include "vh_dev.h"
+#include <algorithm>
 
 namespace {
 
@@ -29,11 +30,11 @@ __device__ __forceinline__ int32_t feature_bin(const int32_t *__restrict__ f, co
 __global__ void bin_hist_kernel(VhSets s, int32_t set0) {
   const int32_t set = set0 + blockIdx.y;
   const int32_t n = min(s.count[set], s.cap);
-  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t *f = s.feat + ((int64_t)set * s.cap + i) * 12;
-  atomicAdd(&s.hist[(int64_t)set * s.nbins + feature_bin(f, s)], 1);
-  atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + f[3] * s.H + f[1]], 1);
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t *f = s.feat + ((int64_t)set * s.cap + i) * 12;
+    atomicAdd(&s.hist[(int64_t)set * s.nbins + feature_bin(f, s)], 1);
+    atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + f[3] * s.H + f[1]], 1);
+  }
 }
 
 // One workgroup per set: exclusive scan of the histogram into bin_start, and
@@ -125,11 +126,11 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
 __global__ void bin_fill_kernel(VhSets s, int32_t set0) {
   const int32_t set = set0 + blockIdx.y;
   const int32_t n = min(s.count[set], s.cap);
-  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t b = feature_bin(s.feat + ((int64_t)set * s.cap + i) * 12, s);
-  const int32_t slot = s.bin_start[(int64_t)set * (s.nbins + 1) + b] + atomicAdd(&s.cursor[(int64_t)set * s.nbins + b], 1);
-  s.tmp_idx[(int64_t)set * s.cap + slot] = i;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t b = feature_bin(s.feat + ((int64_t)set * s.cap + i) * 12, s);
+    const int32_t slot = s.bin_start[(int64_t)set * (s.nbins + 1) + b] + atomicAdd(&s.cursor[(int64_t)set * s.nbins + b], 1);
+    s.tmp_idx[(int64_t)set * s.cap + slot] = i;
+  }
 }
 
 // One wave per bin: the atomic fill left the bin's members in arbitrary order;
@@ -205,15 +206,20 @@ __global__ void ref_index_kernel(VhSets s, int32_t set, int32_t *__restrict__ bs
 
 }  // namespace
 
+// Per-feature kernels use a grid-stride loop over a fixed, modest number of
+// workgroups per set: the feature count lives on the device and a cap-sized
+// grid would be ~75 % empty workgroups at typical densities.
+static int32_t feature_blocks(const VhSets &s) { return std::min(std::max(s.cap / 1024, 8), 256); }
+
 void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
-  dim3 grid((s.cap + 255) / 256, nsets);
+  dim3 grid(feature_blocks(s), nsets);
   hipLaunchKernelGGL(bin_hist_kernel, grid, dim3(256), 0, st, s, set0);
 }
 void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
   hipLaunchKernelGGL(bin_scan_kernel, dim3(nsets), dim3(1024), 0, st, s, set0);
 }
 void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
-  dim3 grid((s.cap + 255) / 256, nsets);
+  dim3 grid(feature_blocks(s), nsets);
   hipLaunchKernelGGL(bin_fill_kernel, grid, dim3(256), 0, st, s, set0);
 }
 void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {

@@ -41,7 +41,7 @@ __global__ void half_res_kernel(VhImages src, uint8_t *__restrict__ dst, VhGeom 
 }
 
 // --------------------------------------------------------------- detect_nms
-// LDS: sI[IH][IWp] u8 | sF1[FH][FWp] i16 | sF2[FH][FWp] i16
+// LDS: sI[IH][IWp] u8 | sF1[FH][FWp] i16 | sF2[FH][FWp] i16 | work-list count, entries | codes
 //
 // Tile geometry (n = nms_n): the tile owns tbx x tby NMS blocks whose first
 // pixel is (n+7 + bx0*(n+1), n+7 + by0*(n+1)); responses are needed n pixels
@@ -107,55 +107,227 @@ detect_nms_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__
   }
   __syncthreads();
 
-  // 3. NMS, one lane per block (Neubeck/Van Gool alg. 4, matcher.cpp:381-466)
-  if (tid >= g.tbx * g.tby) return;
-  const int32_t lby = tid / g.tbx, lbx = tid - lby * g.tbx;
-  const int32_t bx = bx0 + lbx, by = by0 + lby;
-  if (bx >= g.nbx || by >= g.nby) return;
-  const int32_t fx = n + lbx * n1, fy = n + lby * n1;  // block origin in response-tile coords
+  // 3. NMS (Neubeck/Van Gool alg. 4, matcher.cpp:381-466) in two steps so that
+  //    lanes stay busy: (a) one lane per block finds the block's four extrema and
+  //    applies the threshold -- ~95 % of (block, class) candidates die here --
+  //    and appends survivors to an LDS work list; (b) the list is processed
+  //    densely, one lane per surviving candidate, for the (2n+1)^2 dominance test.
+  int32_t *sCnt = (int32_t *)(sF2 + (size_t)g.FH * g.FWp);      // work-list length
+  uint32_t *sWork = (uint32_t *)(sCnt + 1);                      // [4*tbx*tby] ex | ey<<10 | c<<20 | lane<<22
+  uint16_t *sCode = (uint16_t *)(sWork + 4 * g.tbx * g.tby);     // [tbx*tby][4] position codes
+  const int32_t nblk_tile = g.tbx * g.tby;
+  if (tid == 0) *sCnt = 0;
+  for (int32_t k = tid; k < 4 * nblk_tile; k += 256) sCode[k] = VH_NO_CODE;
+  __syncthreads();
   // clip limits W-1-margin / H-1-margin in response-tile coords (matcher.cpp:420-421)
   const int32_t xlim = (g.Wm - 1 - VH_MARGIN) - fx0, ylim = (g.Hm - 1 - VH_MARGIN) - fy0;
-
-  int32_t ex[4], ey[4], ev[4];
-  ex[0] = ex[1] = ex[2] = ex[3] = fx;
-  ey[0] = ey[1] = ey[2] = ey[3] = fy;
-  ev[0] = ev[1] = sF1[(size_t)fy * g.FWp + fx];
-  ev[2] = ev[3] = sF2[(size_t)fy * g.FWp + fx];
-  for (int32_t j2 = fy; j2 <= fy + n; j2++) {
-    for (int32_t i2 = fx; i2 <= fx + n; i2++) {
-      int32_t cur = sF1[(size_t)j2 * g.FWp + i2];
-      if (cur < ev[0]) { ex[0] = i2; ey[0] = j2; ev[0] = cur; }       // first extremum in scan order wins
-      else if (cur > ev[1]) { ex[1] = i2; ey[1] = j2; ev[1] = cur; }  // (matcher.cpp:397-405)
-      cur = sF2[(size_t)j2 * g.FWp + i2];
-      if (cur < ev[2]) { ex[2] = i2; ey[2] = j2; ev[2] = cur; }
-      else if (cur > ev[3]) { ex[3] = i2; ey[3] = j2; ev[3] = cur; }
-    }
-  }
-  uint64_t code = 0;
-  int32_t cnt = 0;
-#pragma unroll
-  for (int32_t c = 0; c < 4; c++) {
-    const int16_t *F = (c < 2) ? sF1 : sF2;
-    const bool is_min = (c & 1) == 0;
-    const int32_t val = ev[c];
-    bool ok = is_min ? (val <= -g.tau) : (val >= g.tau);  // threshold (matcher.cpp:427,439,451,463)
-    if (ok) {
-      const int32_t jhi = min(ey[c] + n, ylim), ihi = min(ex[c] + n, xlim);
-      for (int32_t j2 = ey[c] - n; j2 <= jhi && ok; j2++) {
-        for (int32_t i2 = ex[c] - n; i2 <= ihi; i2++) {
-          const int32_t cur = F[(size_t)j2 * g.FWp + i2];
-          const bool outside = (i2 < fx) | (i2 > fx + n) | (j2 < fy) | (j2 > fy + n);
-          if (outside && (is_min ? (cur < val) : (cur > val))) { ok = false; break; }
-        }
+  const int32_t lby = tid / g.tbx, lbx = tid - lby * g.tbx;
+  const int32_t bx = bx0 + lbx, by = by0 + lby;
+  const bool have_block = tid < nblk_tile && bx < g.nbx && by < g.nby;
+  if (have_block) {
+    const int32_t fx = n + lbx * n1, fy = n + lby * n1;  // block origin in response-tile coords
+    int32_t ex[4], ey[4], ev[4];
+    ex[0] = ex[1] = ex[2] = ex[3] = fx;
+    ey[0] = ey[1] = ey[2] = ey[3] = fy;
+    ev[0] = ev[1] = sF1[(size_t)fy * g.FWp + fx];
+    ev[2] = ev[3] = sF2[(size_t)fy * g.FWp + fx];
+    for (int32_t j2 = fy; j2 <= fy + n; j2++) {
+      for (int32_t i2 = fx; i2 <= fx + n; i2++) {
+        int32_t cur = sF1[(size_t)j2 * g.FWp + i2];
+        if (cur < ev[0]) { ex[0] = i2; ey[0] = j2; ev[0] = cur; }       // first extremum in scan order wins
+        else if (cur > ev[1]) { ex[1] = i2; ey[1] = j2; ev[1] = cur; }  // (matcher.cpp:397-405)
+        cur = sF2[(size_t)j2 * g.FWp + i2];
+        if (cur < ev[2]) { ex[2] = i2; ey[2] = j2; ev[2] = cur; }
+        else if (cur > ev[3]) { ex[3] = i2; ey[3] = j2; ev[3] = cur; }
       }
     }
-    const uint32_t pc = ok ? (uint32_t)((ey[c] - fy) * n1 + (ex[c] - fx)) : VH_NO_CODE;
-    code |= (uint64_t)pc << (16 * c);
-    cnt += ok ? 1 : 0;
+#pragma unroll
+    for (int32_t c = 0; c < 4; c++) {
+      // threshold (matcher.cpp:427,439,451,463); order vs the dominance test is immaterial
+      const bool pass = (c & 1) ? (ev[c] >= g.tau) : (ev[c] <= -g.tau);
+      if (pass) sWork[atomicAdd(sCnt, 1)] = (uint32_t)ex[c] | ((uint32_t)ey[c] << 10) | ((uint32_t)c << 20) | ((uint32_t)tid << 22);
+    }
   }
-  const int32_t blk = by * g.nbx + bx;
-  rec[(int64_t)id * g.nblocks + blk] = code;
-  if (cnt) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + blk / VH_CHUNK], cnt);
+  __syncthreads();
+  const int32_t nwork = *sCnt;
+  for (int32_t w = tid; w < nwork; w += 256) {
+    const uint32_t e = sWork[w];
+    const int32_t cx = e & 1023, cy = (e >> 10) & 1023, c = (e >> 20) & 3, owner = e >> 22;
+    const int32_t oby = owner / g.tbx, obx = owner - oby * g.tbx;
+    const int32_t fx = n + obx * n1, fy = n + oby * n1;
+    const int16_t *F = (c < 2) ? sF1 : sF2;
+    const bool is_min = (c & 1) == 0;
+    const int32_t val = F[(size_t)cy * g.FWp + cx];
+    const int32_t jhi = min(cy + n, ylim), ihi = min(cx + n, xlim);
+    bool ok = true;
+    for (int32_t j2 = cy - n; j2 <= jhi && ok; j2++) {
+      for (int32_t i2 = cx - n; i2 <= ihi; i2++) {
+        const int32_t cur = F[(size_t)j2 * g.FWp + i2];
+        const bool outside = (i2 < fx) | (i2 > fx + n) | (j2 < fy) | (j2 > fy + n);
+        if (outside && (is_min ? (cur < val) : (cur > val))) { ok = false; break; }
+      }
+    }
+    if (ok) sCode[owner * 4 + c] = (uint16_t)((cy - fy) * n1 + (cx - fx));
+  }
+  __syncthreads();
+  if (have_block) {
+    uint64_t code = 0;
+    int32_t cnt = 0;
+#pragma unroll
+    for (int32_t c = 0; c < 4; c++) {
+      const uint32_t pc = sCode[tid * 4 + c];
+      code |= (uint64_t)pc << (16 * c);
+      cnt += pc != VH_NO_CODE ? 1 : 0;
+    }
+    const int32_t blk = by * g.nbx + bx;
+    rec[(int64_t)id * g.nblocks + blk] = code;
+    if (cnt) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + blk / VH_CHUNK], cnt);
+  }
+}
+
+// ---------------------------------------------------------- detect_nms (fast)
+// Same algorithm with nms_n as a compile-time constant (the values that occur in
+// practice: 1..4) so that every LDS offset is an immediate and every loop is
+// unrolled, and with the image tile staged by aligned 4-byte loads.  Requires
+// 4-byte aligned rows (base, bpl and stream stride multiples of 4); anything
+// else takes the generic kernel above.
+template <int N> struct DetTile {
+  static constexpr int N1 = N + 1, TBX = 32, TBY = 8;
+  static constexpr int FW = TBX * N1 + 2 * N, FH = TBY * N1 + 2 * N;
+  static constexpr int IW = FW + 4, IH = FH + 4;
+  static constexpr int DW = (IW + 3 + 3) / 4;  // dwords per staged row (room for the 0..3 byte alignment offset)
+  static constexpr int IP = DW * 4;
+  static constexpr int FP = FW + (FW & 1);     // response row pitch (i16), kept even
+  static constexpr int NSEG = (256 / FW) > 0 ? (256 / FW) : 1;
+  static constexpr int ROWS = (FH + NSEG - 1) / NSEG;
+};
+
+template <int N>
+__global__ void __launch_bounds__(256)
+detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__restrict__ chunk_count) {
+  using T = DetTile<N>;
+  constexpr int N1 = T::N1;
+  __shared__ __attribute__((aligned(16))) uint8_t sI[T::IH * T::IP];
+  __shared__ __attribute__((aligned(16))) int16_t sF1[T::FH * T::FP];
+  __shared__ __attribute__((aligned(16))) int16_t sF2[T::FH * T::FP];
+  __shared__ uint32_t sWork[4 * 256];
+  __shared__ uint16_t sCode[4 * 256];
+  __shared__ int32_t sCnt;
+
+  const int32_t id = blockIdx.z, tid = threadIdx.x;
+  const uint8_t *__restrict__ I = vh_image_ptr(im, id);
+  const int32_t bx0 = blockIdx.x * T::TBX, by0 = blockIdx.y * T::TBY;
+  const int32_t fx0 = VH_MARGIN + bx0 * N1, fy0 = VH_MARGIN + by0 * N1;
+  const int32_t ix0 = fx0 - 2, iy0 = fy0 - 2;
+  const int32_t ax0 = ix0 & ~3, off = ix0 & 3;
+
+  // 1. stage the image tile with aligned dword loads (zero outside the image)
+  if (tid == 0) sCnt = 0;
+  for (int32_t k = tid; k < T::IH * T::DW; k += 256) {
+    const int32_t r = k / T::DW, c = k - r * T::DW;
+    const int32_t gy = iy0 + r, gx = ax0 + 4 * c;
+    uint32_t v = 0;
+    if (gy < g.Hm && gx < g.bplm) v = *(const uint32_t *)(I + (int64_t)gy * g.bplm + gx);
+    ((uint32_t *)sI)[k] = v;
+  }
+#pragma unroll
+  for (int32_t k = 0; k < 4; k++) sCode[tid * 4 + k] = VH_NO_CODE;
+  __syncthreads();
+
+  // 2. blob / checkerboard responses: one column per lane, sliding 5-row window
+  for (int32_t task = tid; task < T::FW * T::NSEG; task += 256) {
+    const int32_t seg = task / T::FW, cx = task - seg * T::FW;
+    const int32_t r0 = seg * T::ROWS;
+    const uint8_t *p = sI + r0 * T::IP + off + cx;
+    int32_t h5[5], h3[5], hc[5], cc[5];
+#pragma unroll
+    for (int32_t k = 0; k < 4; k++) {
+      const int32_t a = p[k * T::IP + 0], b = p[k * T::IP + 1], c = p[k * T::IP + 2], d = p[k * T::IP + 3], e = p[k * T::IP + 4];
+      h5[k + 1] = a + b + c + d + e; h3[k + 1] = b + c + d; hc[k + 1] = a + b - d - e; cc[k + 1] = c;
+    }
+#pragma unroll
+    for (int32_t i = 0; i < T::ROWS; i++) {
+      const int32_t fr = r0 + i;
+      if (fr < T::FH) {
+#pragma unroll
+        for (int32_t k = 0; k < 4; k++) { h5[k] = h5[k + 1]; h3[k] = h3[k + 1]; hc[k] = hc[k + 1]; cc[k] = cc[k + 1]; }
+        const uint8_t *q = p + (i + 4) * T::IP;
+        const int32_t a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+        h5[4] = a + b + c + d + e; h3[4] = b + c + d; hc[4] = a + b - d - e; cc[4] = c;
+        // f2 = (1,1,0,-1,-1)^T (x) (1,1,0,-1,-1)   (filter.cpp:339-347,:365-367)
+        // f1 = -S5x5 + 2*S3x3 + 7*centre            (filter.cpp:461-463)
+        sF2[fr * T::FP + cx] = (int16_t)(hc[0] + hc[1] - hc[3] - hc[4]);
+        sF1[fr * T::FP + cx] = (int16_t)(-(h5[0] + h5[1] + h5[2] + h5[3] + h5[4]) + 2 * (h3[1] + h3[2] + h3[3]) + 7 * cc[2]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // 3a. block extrema + threshold, one lane per NMS block (matcher.cpp:384-417,
+  //     threshold :427,:439,:451,:463); survivors go to the work list
+  const int32_t lby = tid / T::TBX, lbx = tid % T::TBX;
+  const int32_t bx = bx0 + lbx, by = by0 + lby;
+  const bool have_block = bx < g.nbx && by < g.nby;
+  const int32_t fx = N + lbx * N1, fy = N + lby * N1;
+  if (have_block) {
+    const int16_t *b1 = sF1 + fy * T::FP + fx, *b2 = sF2 + fy * T::FP + fx;
+    int32_t v1n = b1[0], v1x = v1n, v2n = b2[0], v2x = v2n, p1n = 0, p1x = 0, p2n = 0, p2x = 0;
+#pragma unroll
+    for (int32_t j = 0; j < N1; j++) {
+#pragma unroll
+      for (int32_t i = 0; i < N1; i++) {
+        const int32_t k = j * N1 + i;
+        int32_t cur = b1[j * T::FP + i];
+        if (cur < v1n) { v1n = cur; p1n = k; } else if (cur > v1x) { v1x = cur; p1x = k; }  // first extremum wins
+        cur = b2[j * T::FP + i];
+        if (cur < v2n) { v2n = cur; p2n = k; } else if (cur > v2x) { v2x = cur; p2x = k; }
+      }
+    }
+    if (v1n <= -g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (0u << 8) | ((uint32_t)p1n << 10);
+    if (v1x >= g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (1u << 8) | ((uint32_t)p1x << 10);
+    if (v2n <= -g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (2u << 8) | ((uint32_t)p2n << 10);
+    if (v2x >= g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (3u << 8) | ((uint32_t)p2x << 10);
+  }
+  __syncthreads();
+
+  // 3b. dominance test over the (2N+1)^2 window, clipped at W-1-margin /
+  //     H-1-margin, ignoring the candidate's own block (matcher.cpp:420-426)
+  const int32_t nwork = sCnt;
+  const int32_t xlim = (g.Wm - 1 - VH_MARGIN) - fx0, ylim = (g.Hm - 1 - VH_MARGIN) - fy0;
+  for (int32_t w = tid; w < nwork; w += 256) {
+    const uint32_t e = sWork[w];
+    const int32_t owner = e & 255, c = (e >> 8) & 3, pos = e >> 10;
+    const int32_t dy = pos / N1, dx = pos - dy * N1;
+    const int32_t ofx = N + (owner % T::TBX) * N1, ofy = N + (owner / T::TBX) * N1;
+    const int32_t cx = ofx + dx, cy = ofy + dy;
+    const int16_t *F = ((c < 2) ? sF1 : sF2) + cy * T::FP + cx;
+    const int32_t sgn = (c & 1) ? -1 : 1;  // maxima are tested as minima of the negated response
+    const int32_t val = sgn * (int32_t)F[0];
+    bool fail = false;
+#pragma unroll
+    for (int32_t j = -N; j <= N; j++) {
+      const bool row_in = (uint32_t)(dy + j) <= (uint32_t)N, row_ok = cy + j <= ylim;
+#pragma unroll
+      for (int32_t i = -N; i <= N; i++) {
+        const bool col_in = (uint32_t)(dx + i) <= (uint32_t)N;
+        const int32_t cur = sgn * (int32_t)F[j * T::FP + i];
+        fail |= row_ok & (cx + i <= xlim) & !(row_in & col_in) & (cur < val);
+      }
+    }
+    if (!fail) sCode[owner * 4 + c] = (uint16_t)pos;
+  }
+  __syncthreads();
+
+  // 4. 8 bytes per block + the per-chunk survivor count
+  if (have_block) {
+    const uint2 cw = *(const uint2 *)(sCode + tid * 4);
+    int32_t cnt = 0;
+#pragma unroll
+    for (int32_t c = 0; c < 4; c++) cnt += sCode[tid * 4 + c] != VH_NO_CODE ? 1 : 0;
+    const int32_t blk = by * g.nbx + bx;
+    rec[(int64_t)id * g.nblocks + blk] = (uint64_t)cw.x | ((uint64_t)cw.y << 32);
+    if (cnt) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + blk / VH_CHUNK], cnt);
+  }
 }
 
 // ------------------------------------------------------------- emit_features
@@ -330,8 +502,21 @@ void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipS
 void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, int32_t *chunk_count,
                           hipStream_t st) {
   if (g.nblocks <= 0) return;
+  const bool aligned = (g.bplm % 4 == 0) && (im.stride % 4 == 0) && ((uintptr_t)im.base[0] % 4 == 0) &&
+                       (im.ncam < 2 || (uintptr_t)im.base[1] % 4 == 0);
+  if (aligned && g.n >= 1 && g.n <= 4) {
+    dim3 grid((g.nbx + 31) / 32, (g.nby + 7) / 8, im.S * im.ncam);
+    switch (g.n) {
+      case 1: hipLaunchKernelGGL(detect_nms_fast_kernel<1>, grid, dim3(256), 0, st, im, g, rec, chunk_count); break;
+      case 2: hipLaunchKernelGGL(detect_nms_fast_kernel<2>, grid, dim3(256), 0, st, im, g, rec, chunk_count); break;
+      case 3: hipLaunchKernelGGL(detect_nms_fast_kernel<3>, grid, dim3(256), 0, st, im, g, rec, chunk_count); break;
+      default: hipLaunchKernelGGL(detect_nms_fast_kernel<4>, grid, dim3(256), 0, st, im, g, rec, chunk_count); break;
+    }
+    return;
+  }
   dim3 grid((g.nbx + g.tbx - 1) / g.tbx, (g.nby + g.tby - 1) / g.tby, im.S * im.ncam);
-  const size_t lds = (size_t)g.IH * g.IWp + 2 * (size_t)g.FH * g.FWp * sizeof(int16_t);
+  const size_t lds = (size_t)g.IH * g.IWp + 2 * (size_t)g.FH * g.FWp * sizeof(int16_t) + 4 +
+                     (size_t)g.tbx * g.tby * (16 + 8);
   hipLaunchKernelGGL(detect_nms_kernel, grid, dim3(256), lds, st, im, g, rec, chunk_count);
 }
 

@@ -21,6 +21,7 @@
 //    because a candidate inside a lane's window always lies inside that lane's
 //    bin range.
 #include "vh_dev.h"
+#include <algorithm>
 
 #ifndef VH_SB
 #define VH_SB 4
@@ -157,14 +158,20 @@ match_stereo_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
   const int32_t nq = min(s.count[qset], s.cap);
-  const int32_t q = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const int32_t sub = threadIdx.x & 15;
+  // the loop bound is uniform per 16-lane group; whole groups retire together
+  for (int32_t q = (blockIdx.x * 256 + threadIdx.x) >> 4; q < ((nq + 3) & ~3); q += gridDim.x * 16) {
   const bool live = q < nq;
   const int32_t ql = live ? q : 0;
-  const int32_t orig = s.s_idx[(int64_t)qset * s.cap + ql];
-  const uint32_t uv1 = s.s_uv[(int64_t)qset * s.cap + ql];
+  // dead groups (q >= nq) must not follow indices read from never-written memory
+  const int32_t orig = live ? s.s_idx[(int64_t)qset * s.cap + ql] : 0;
+  const uint32_t uv1 = live ? s.s_uv[(int64_t)qset * s.cap + ql] : 0;
   const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
   const uint4 a0 = qdesc[2 * (int64_t)ql], a1 = qdesc[2 * (int64_t)ql + 1];
-  const int32_t c = s.feat[((int64_t)qset * s.cap + orig) * 12 + 3];
+  // class of a bin-ordered position: bins are class-major
+  const int32_t *__restrict__ qbs = s.bin_start + (int64_t)qset * (s.nbins + 1);
+  const int32_t per_class = s.ubn * s.vbn;
+  const int32_t c = (ql >= qbs[per_class] ? 1 : 0) + (ql >= qbs[2 * per_class] ? 1 : 0) + (ql >= qbs[3 * per_class] ? 1 : 0);
   const int32_t u1 = uv1 & 0xFFFF, v1 = uv1 >> 16;
   const int32_t v_lo = max(v1 - a.disp_tol, 0), v_hi = min(v1 + a.disp_tol, s.H - 1);
   const int32_t *__restrict__ crs = s.row_start + (int64_t)cset * (4 * s.H + 1) + c * s.H;
@@ -194,6 +201,7 @@ match_stereo_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const int32_t res = (best_key == 0xFFFFFFFFu) ? 0 : s.s_idx[(int64_t)cset * s.cap + (best_key & 0x7FFFFu)];
     best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + orig] = res;
   }
+  }  // query loop
 }
 
 // ---------------------------------------------------------------------- chain
@@ -211,7 +219,6 @@ match_stereo_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
 __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int32_t *__restrict__ best,
                              int4 *__restrict__ chain, uint32_t *__restrict__ mask, uint32_t epoch) {
   const int32_t stream = blockIdx.y;
-  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const int32_t set1p = vh_role_set(a.S, a.pair_cur, stream, 0), set2p = vh_role_set(a.S, a.pair_cur, stream, 1);
   const int32_t set1c = vh_role_set(a.S, a.pair_cur, stream, 2), set2c = vh_role_set(a.S, a.pair_cur, stream, 3);
   const int32_t n1p = min(s.count[set1p], s.cap), n2p = min(s.count[set2p], s.cap);
@@ -219,8 +226,9 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
   const int32_t *__restrict__ T = best + (int64_t)stream * 4 * s.cap;
   const int64_t cap = s.cap;
   int4 *__restrict__ out = chain + (int64_t)stream * s.cap;
+  const int32_t ndrive = (method == 2) ? n1p : n1c;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ndrive; i += gridDim.x * blockDim.x) {
   if (method == 0) {
-    if (i >= n1c) return;
     int4 r = make_int4(-1, -1, -2, -1);
     if (n1p > 0) {
       const int32_t i1p = T[0 * cap + i];
@@ -234,7 +242,6 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
     }
     out[i] = r;
   } else if (method == 1) {
-    if (i >= n1c) return;
     int4 r = make_int4(-1, -1, -2, -1);
     if (n2c > 0) {
       const int32_t i2c = T[0 * cap + i];
@@ -244,7 +251,6 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
     }
     out[i] = r;
   } else {
-    if (i >= n1p) return;
     int4 r = make_int4(-1, -1, -2, -1);
     if (n2p > 0 && n1c > 0 && n2c > 0) {
       const int32_t i2p = T[0 * cap + i];
@@ -257,6 +263,7 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
     }
     out[i] = r;
   }
+  }  // grid-stride loop
 }
 
 // --------------------------------------------------------------- emit_matches
@@ -340,7 +347,7 @@ static VhMatchArgs filter_passes(const VhMatchArgs &a, int32_t flow) {
 void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
   const VhMatchArgs sr = filter_passes(a, 0);
   if (!sr.npass) return;
-  dim3 grid((s.cap + 15) / 16, sr.npass, a.S);  // 16 queries per workgroup
+  dim3 grid(std::min(std::max(s.cap / 32, 64), 4096), sr.npass, a.S);  // 16 queries per workgroup per trip
   hipLaunchKernelGGL(match_stereo_kernel, grid, dim3(256), 0, st, s, sr, best);
 }
 void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
@@ -351,7 +358,7 @@ void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, 
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, hipStream_t st) {
-  dim3 grid((s.cap + 255) / 256, a.S);
+  dim3 grid(std::min(std::max(s.cap / 1024, 8), 256), a.S);
   hipLaunchKernelGGL(chain_kernel, grid, dim3(256), 0, st, s, a, method, best, chain, mask, epoch);
 }
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
