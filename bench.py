@@ -41,9 +41,7 @@ def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
     phase-shifted so that no two streams of a rank see identical frames."""
     bpl = pkg.synth.bytes_per_line(W)
     out = np.zeros((n_frames, 2, n_streams, H, bpl), np.uint8)
-    for s in range(n_streams):
-        gs = rank * n_streams + s
-        seed, phase = 1 + gs % 8, gs // 8
+    for s, (gs, seed, phase) in enumerate(stream_assignment(rank, n_streams)):
         for t in range(n_frames):
             k = t + phase
             dx, dy = (5 * k) % 20, k % 20
@@ -79,6 +77,56 @@ def cpu_baseline(ob, frames, dims, budget_s: float):
     return pairs / dt, pairs, dt, results
 
 
+def stream_assignment(rank: int, n_streams: int):
+    """Global stream ids owned by `rank` and their (seed, phase): streams are
+    independent camera sequences, sharded rank-major with no overlap."""
+    out = []
+    for s in range(n_streams):
+        gs = rank * n_streams + s
+        out.append((gs, 1 + gs % 8, gs // 8))
+    return out
+
+
+def dist_selftest(args):
+    """world_size>1 on CPU (gloo): every rank takes its own streams, ranks meet
+    at a barrier, time a fake step loop, and rank 0 reports the whole-job value
+    from the MAX over ranks -- the same control flow as the GPU bench."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = entry.load_package()
+    S = args.streams
+    mine = stream_assignment(rank, S)
+    # tiny frames of this rank's streams: the sharding must give different data per rank
+    digest = 0
+    for gs, seed, phase in mine[:2]:
+        digest ^= pkg.synth.fnv1a64(pkg.synth.frame(64, 32, phase % 20, 0, 2, 1, seed)[:4])
+    ids = torch.tensor([m[0] for m in mine], dtype=torch.int64)
+    gathered = [torch.zeros_like(ids) for _ in range(world)]
+    dist.all_gather(gathered, ids)
+    all_ids = torch.cat(gathered).tolist()
+    dig = torch.tensor([digest & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64)
+    digs = [torch.zeros_like(dig) for _ in range(world)]
+    dist.all_gather(digs, dig)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))  # ranks finish at different times: the slowest one must set the clock
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([0.05 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "streams_per_gpu": S,
+                          "global_stream_ids": all_ids, "distinct_data": len({int(d.item()) for d in digs}) == world,
+                          "max_rank_time": float(tt.item()), "wall": dt,
+                          "value": world * S * args.steps / float(tt.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,7 +137,11 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct frames per stream kept in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
     args = ap.parse_args()
+    if args.dist_selftest:
+        return dist_selftest(args)
 
     import torch
     import torch.distributed as dist
