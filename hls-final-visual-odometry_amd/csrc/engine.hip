@@ -147,6 +147,7 @@ struct Group {
     sets.nbins = 4 * sets.ubn * sets.vbn;
     sets.max_tiles = cap / 64 + 4 * sets.ubn + 1;
     sets.W = dims[0]; sets.H = dims[1];
+    sets.tile_span = (2 * p.match_radius >= dims[1]) ? sets.ubn * sets.vbn : sets.vbn;
     const size_t ns = 4 * (size_t)S;
     if ((rc = dmalloc(&sets.feat, ns * cap * 12, false))) return rc;
     if ((rc = dmalloc(&sets.s_uv, ns * cap, false))) return rc;

@@ -68,15 +68,19 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
   if (tid == 0) bs[s.nbins] = sCarry;
   __syncthreads();
 
-  // query tiles: column (c,ub) owns positions [bs[col*vbn], bs[(col+1)*vbn])
-  const int32_t ncol = 4 * s.ubn;
+  // query tiles: <= 64 consecutive bin-ordered queries of one tile group.  A
+  // group is one (class, u-bin) column, or -- when the v search window covers
+  // the whole image anyway (2*radius >= H), so that mixing columns cannot widen
+  // the v range a wave has to walk -- a whole class, which fills the lanes of
+  // almost every wave (column remainders would leave ~25 % of them idle).
+  const int32_t ngroup = s.nbins / s.tile_span;
   int4 *__restrict__ tiles = s.tiles + (int64_t)set * s.max_tiles;
   if (tid == 0) sCarry = 0;
   __syncthreads();
-  for (int32_t c0 = 0; c0 < ncol; c0 += 1024) {
-    const int32_t col = c0 + tid;
+  for (int32_t c0 = 0; c0 < ngroup; c0 += 1024) {
+    const int32_t grp = c0 + tid;
     int32_t q0 = 0, q1 = 0;
-    if (col < ncol) { q0 = bs[col * s.vbn]; q1 = bs[(col + 1) * s.vbn]; }
+    if (grp < ngroup) { q0 = bs[grp * s.tile_span]; q1 = bs[(grp + 1) * s.tile_span]; }
     const int32_t nt = (q1 - q0 + 63) >> 6;
     sPart[tid] = nt;
     __syncthreads();
@@ -88,8 +92,9 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
     }
     const int32_t incl = sPart[tid], carry = sCarry;
     int32_t t0 = carry + incl - nt;
+    const int32_t cls = (grp * s.tile_span) / (s.ubn * s.vbn);
     for (int32_t k = 0; k < nt; k++, t0++)
-      if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + 64 * k, min(q1, q0 + 64 * k + 64), col / s.ubn, col % s.ubn);
+      if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + 64 * k, min(q1, q0 + 64 * k + 64), cls, 0);
     __syncthreads();
     if (tid == 1023) sCarry = carry + incl;
     __syncthreads();

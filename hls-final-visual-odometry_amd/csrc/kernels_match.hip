@@ -23,6 +23,9 @@
 #include "vh_dev.h"
 #include <algorithm>
 
+#ifndef VH_MATCH_LDS
+#define VH_MATCH_LDS 1
+#endif
 #ifndef VH_SB
 #define VH_SB 4
 #endif
@@ -50,6 +53,10 @@ __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) {
 
 __global__ void __launch_bounds__(256)
 match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
+#if VH_MATCH_LDS
+  __shared__ uint4 sDesc[4 * 128];
+  __shared__ uint32_t sUv[4 * 64];
+#endif
   const int32_t pass = blockIdx.y, stream = blockIdx.z;
   const int32_t lane = threadIdx.x & 63;
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
@@ -112,6 +119,36 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const uint32_t key = out ? 0xFFFFFFFFu : ((sad << 19) | (uint32_t)p);
     best_key = min(best_key, key);
   };
+#if VH_MATCH_LDS
+  // Candidate stream through a wave-private LDS chunk: lane j of the wave fetches
+  // candidate p+j (coalesced 36 B per lane), the chunk is then consumed with
+  // broadcast reads so that v_sad_u8 runs on VGPR operands (its SGPR-operand form
+  // issues ~13 % slower, tools/ubench_valu.hip) and no scalar-load round trips
+  // sit in the loop.  The next chunk's global loads are in flight while the
+  // current one is consumed.
+  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;   // [64][2] uint4
+  uint32_t *wU = sUv + (threadIdx.x >> 6) * 64;   // [64]
+  for (int32_t ub = UB0; ub <= UB1; ub++) {
+    const int32_t row = (c * s.ubn + ub) * s.vbn;
+    const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
+    const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + VB1 + 1]);
+    for (int32_t pc = p0; pc < p1; pc += 64) {
+      const int32_t mcnt = min(64, p1 - pc);
+      const int32_t pl = min(pc + lane, p1 - 1);
+      const uint32_t gu = cuv[pl];
+      const uint4 g0 = cdesc[2 * (int64_t)pl], g1 = cdesc[2 * (int64_t)pl + 1];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
+      wU[lane] = gu; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
+      int32_t j = 0;
+      for (; j + 4 <= mcnt; j += 4) {
+#pragma unroll
+        for (int32_t k = 0; k < 4; k++) consider(wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], pc + j + k);
+      }
+      for (; j < mcnt; j++) consider(wU[j], wD[2 * j], wD[2 * j + 1], pc + j);
+    }
+  }
+#else
   for (int32_t ub = UB0; ub <= UB1; ub++) {
     const int32_t row = (c * s.ubn + ub) * s.vbn;
     const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
@@ -132,6 +169,7 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     }
     for (; p < p1; p++) consider(cuv[p], cdesc[2 * (int64_t)p], cdesc[2 * (int64_t)p + 1], p);
   }
+#endif
   const int32_t best_pos = (best_key == 0xFFFFFFFFu) ? -1 : (int32_t)(best_key & 0x7FFFFu);
   if (valid) {
     // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)

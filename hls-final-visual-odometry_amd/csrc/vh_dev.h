@@ -69,6 +69,7 @@ struct VhSets {
   int32_t *tile_cnt; // [set]
   int32_t cap, nbins, ubn, vbn, binsize, max_tiles;
   int32_t W, H;      // dims_c of the matcher (full resolution)
+  int32_t tile_span; // bins per tile group: vbn (one (class,u-bin) column) or ubn*vbn (a whole class)
 };
 
 struct VhPass {
