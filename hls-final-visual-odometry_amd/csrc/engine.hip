@@ -147,6 +147,11 @@ struct Group {
     sets.nbins = 4 * sets.ubn * sets.vbn;
     sets.max_tiles = cap / 64 + 4 * sets.ubn + 1;
     sets.W = dims[0]; sets.H = dims[1];
+    {  // a bin of binsize px meets at most ceil(binsize/block)+1 NMS blocks per axis, one feature per class each
+      const int32_t blk = g.scale * (g.n + 1);
+      const int64_t per_axis = (p.match_binsize + blk - 1) / blk + 1;
+      sets.stage_cap = (int32_t)std::min<int64_t>(per_axis * per_axis, cap);
+    }
     sets.tile_span = (2 * p.match_radius >= dims[1]) ? sets.ubn * sets.vbn : sets.vbn;
     const size_t ns = 4 * (size_t)S;
     if ((rc = dmalloc(&sets.feat, ns * cap * 12, false))) return rc;
@@ -157,6 +162,7 @@ struct Group {
     if ((rc = dmalloc(&sets.hist, ns * sets.nbins, true))) return rc;
     if ((rc = dmalloc(&sets.cursor, ns * sets.nbins, true))) return rc;
     if ((rc = dmalloc(&sets.tmp_idx, ns * cap, false))) return rc;
+    if ((rc = dmalloc(&sets.stage, ns * (size_t)sets.nbins * sets.stage_cap, false))) return rc;
     if ((rc = dmalloc(&sets.count, ns, true))) return rc;
     const size_t nrow = 4 * (size_t)dims[1];
     if ((rc = dmalloc(&sets.row_start, ns * (nrow + 1), true))) return rc;
@@ -203,18 +209,26 @@ struct Group {
   }
 
   // ---- detect + bin ------------------------------------------------------
-  int32_t bin_sets(int32_t set0, int32_t nsets, bool zero_first) {
-    if (zero_first) {
-      VH_HIP(hipMemsetAsync(sets.hist + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
-      VH_HIP(hipMemsetAsync(sets.cursor + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
-      const size_t nrow = 4 * (size_t)dims[1];
-      VH_HIP(hipMemsetAsync(sets.row_hist + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
-      VH_HIP(hipMemsetAsync(sets.row_cursor + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
+  int32_t zero_bin_counters(int32_t set0, int32_t nsets) {
+    const size_t nrow = 4 * (size_t)dims[1];
+    VH_HIP(hipMemsetAsync(sets.hist + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
+    VH_HIP(hipMemsetAsync(sets.cursor + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
+    VH_HIP(hipMemsetAsync(sets.row_hist + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
+    VH_HIP(hipMemsetAsync(sets.row_cursor + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
+    return VH_OK;
+  }
+
+  // staged: the histograms and per-bin member lists were already produced by
+  // emit_features; otherwise (caller-supplied features) build them here.
+  int32_t bin_sets(int32_t set0, int32_t nsets, bool staged) {
+    if (!staged) {
+      int32_t rc = zero_bin_counters(set0, nsets);
+      if (rc) return rc;
+      { Scope sc(this, "bin_hist"); vh_launch_bin_hist(sets, set0, nsets, stream); }
     }
-    { Scope sc(this, "bin_hist"); vh_launch_bin_hist(sets, set0, nsets, stream); }
     { Scope sc(this, "bin_scan"); vh_launch_bin_scan(sets, set0, nsets, stream); }
-    { Scope sc(this, "bin_fill"); vh_launch_bin_fill(sets, set0, nsets, stream); }
-    { Scope sc(this, "bin_sort"); vh_launch_bin_sort(sets, set0, nsets, stream); }
+    if (!staged) { Scope sc(this, "bin_fill"); vh_launch_bin_fill(sets, set0, nsets, stream); }
+    { Scope sc(this, "bin_sort"); vh_launch_bin_sort(sets, set0, nsets, staged ? 1 : 0, stream); }
     VH_HIP(hipGetLastError());
     return VH_OK;
   }
@@ -229,6 +243,7 @@ struct Group {
     const int32_t set0 = pair_cur * 2 * S, nsets = 2 * S;
     VH_HIP(hipMemsetAsync(sets.count + set0, 0, sizeof(int32_t) * nsets, stream));
     VH_HIP(hipMemsetAsync(d_chunk_count, 0, sizeof(int32_t) * 2 * (size_t)S * g.nchunks, stream));
+    if ((rc = zero_bin_counters(set0, nsets))) return rc;
     VhImages im{};
     im.base[0] = (const uint8_t *)dI1; im.base[1] = (const uint8_t *)dI2;
     im.stride = stride; im.ncam = dI2 ? 2 : 1; im.S = S; im.pair_cur = pair_cur;
@@ -241,7 +256,7 @@ struct Group {
       im = hm;
     }
     { Scope sc(this, "detect_nms"); vh_launch_detect_nms(im, g, d_rec, d_chunk_count, stream); }
-    { Scope sc(this, "emit_features"); vh_launch_emit_features(im, g, d_rec, d_chunk_count, sets.feat, sets.count, cap, stream); }
+    { Scope sc(this, "emit_features"); vh_launch_emit_features(im, g, d_rec, d_chunk_count, sets, stream); }
     VH_HIP(hipGetLastError());
     return bin_sets(set0, nsets, true);
   }
@@ -371,7 +386,7 @@ struct Group {
     if (n) VH_HIP(hipMemcpyAsync(sets.feat + (size_t)set * cap * 12, m, sizeof(int32_t) * 12 * (size_t)n, hipMemcpyHostToDevice, stream));
     VH_HIP(hipMemcpyAsync(sets.count + set, &n, sizeof(int32_t), hipMemcpyHostToDevice, stream));
     VH_HIP(hipStreamSynchronize(stream));
-    return bin_sets(set, 1, true);
+    return bin_sets(set, 1, false);
   }
 };
 

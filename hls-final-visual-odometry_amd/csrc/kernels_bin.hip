@@ -141,14 +141,17 @@ __global__ void bin_fill_kernel(VhSets s, int32_t set0) {
 // One wave per bin: the atomic fill left the bin's members in arbitrary order;
 // rank-sort them back to ascending feature index (the reference's push_back
 // order) and gather the bin-ordered structure-of-arrays.
-__global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0) {
+__global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, int32_t staged) {
   const int32_t set = set0 + blockIdx.y;
   const int32_t bin = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (bin >= s.nbins) return;
   const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
   const int32_t p0 = bs[bin], p1 = bs[bin + 1], L = p1 - p0;
   if (L <= 0) return;
-  const int32_t *__restrict__ tmp = s.tmp_idx + (int64_t)set * s.cap;
+  // members of this bin, in arbitrary order: staged by emit_features (own
+  // features) or placed by bin_fill (caller-supplied features)
+  const int32_t *__restrict__ tmp = staged ? s.stage + ((int64_t)set * s.nbins + bin) * s.stage_cap - p0
+                                           : s.tmp_idx + (int64_t)set * s.cap;
   const int32_t *__restrict__ feat = s.feat + (int64_t)set * s.cap * 12;
   int32_t *__restrict__ sidx = s.s_idx + (int64_t)set * s.cap;
   uint32_t *__restrict__ suv = s.s_uv + (int64_t)set * s.cap;
@@ -227,9 +230,9 @@ void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_
   dim3 grid(feature_blocks(s), nsets);
   hipLaunchKernelGGL(bin_fill_kernel, grid, dim3(256), 0, st, s, set0);
 }
-void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
+void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, int32_t staged, hipStream_t st) {
   dim3 grid((s.nbins + 3) / 4, nsets);
-  hipLaunchKernelGGL(bin_sort_kernel, grid, dim3(256), 0, st, s, set0);
+  hipLaunchKernelGGL(bin_sort_kernel, grid, dim3(256), 0, st, s, set0, staged);
 }
 void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, int32_t *list_ref,
                          hipStream_t st) {

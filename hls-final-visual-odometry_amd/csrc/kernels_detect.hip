@@ -348,10 +348,13 @@ __device__ __forceinline__ int32_t wave_incl_scan(int32_t v) {
 __constant__ int8_t c_desc_dx[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
 __constant__ int8_t c_desc_dy[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
 
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256)
 emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
-                     const int32_t *__restrict__ chunk_count, int32_t *__restrict__ feat,
-                     int32_t *__restrict__ count, int32_t cap) {
+                     const int32_t *__restrict__ chunk_count, VhSets s) {
+  int32_t *__restrict__ feat = s.feat;
+  int32_t *__restrict__ count = s.count;
+  const int32_t cap = s.cap;
   __shared__ uint32_t sList[4 * VH_CHUNK];  // u | v<<14 | c<<28 (matching-resolution coords)
   __shared__ int32_t sWave[4];
   __shared__ int32_t sBase;
@@ -420,19 +423,41 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     const int32_t u = e & 0x3FFF, v = (e >> 14) & 0x3FFF, c = e >> 28;
     // 5x5 Sobel pair at (u+dx, v+dy): du = smooth_y (x) deriv_x, dv = deriv_y (x) smooth_x
     // (filter.cpp:288-318 column pass, :132-171 / :79-127 row passes)
-    const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (u + dx - 2);
     int32_t a_du = 0, a_dv = 0;
     if (live) {
+      if (ALIGNED) {
+        // each 5-byte row segment comes from two aligned dwords; the row sums are
+        // byte dot products (v_dot4_u32_u8)
+        const int32_t x0 = u + dx - 2, o8 = (x0 & 3) * 8;
+        const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (x0 & ~3);
+        uint32_t lo[5], hi[5];
 #pragma unroll
-      for (int32_t r = 0; r < 5; r++) {
-        const int32_t a = p[0], b = p[1], cc = p[2], d = p[3], ee = p[4];
-        const int32_t rowD = a + 2 * b - 2 * d - ee;
-        const int32_t rowS = a + 4 * b + 6 * cc + 4 * d + ee;
-        const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
-        const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
-        a_du += sw * rowD;
-        a_dv += dw * rowS;
-        p += g.bplm;
+        for (int32_t r = 0; r < 5; r++) { lo[r] = *(const uint32_t *)(p + (int64_t)r * g.bplm); hi[r] = *(const uint32_t *)(p + (int64_t)r * g.bplm + 4); }
+#pragma unroll
+        for (int32_t r = 0; r < 5; r++) {
+          const uint32_t w = (uint32_t)(((uint64_t)hi[r] << 32 | lo[r]) >> o8);  // bytes x0..x0+3
+          const int32_t ee = (hi[r] >> o8) & 0xFF;                                 // byte x0+4
+          const int32_t rowS = (int32_t)__builtin_amdgcn_udot4(w, 0x04060401u, (uint32_t)ee, false);
+          const int32_t rowD = (int32_t)__builtin_amdgcn_udot4(w, 0x00000201u, 0u, false) -
+                               (int32_t)__builtin_amdgcn_udot4(w, 0x02000000u, (uint32_t)ee, false);
+          const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
+          const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
+          a_du += sw * rowD;
+          a_dv += dw * rowS;
+        }
+      } else {
+        const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (u + dx - 2);
+#pragma unroll
+        for (int32_t r = 0; r < 5; r++) {
+          const int32_t a = p[0], b = p[1], cc = p[2], d = p[3], ee = p[4];
+          const int32_t rowD = a + 2 * b - 2 * d - ee;
+          const int32_t rowS = a + 4 * b + 6 * cc + 4 * d + ee;
+          const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
+          const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
+          a_du += sw * rowD;
+          a_dv += dw * rowS;
+          p += g.bplm;
+        }
       }
     }
     // arithmetic >>7, +128, unsigned saturation (filter.cpp:114-115,124 / :159-160,168)
@@ -451,6 +476,16 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     else word = lo | (hi << 16);
     const int32_t fi = base + f;
     if (live && k < 12 && fi < cap) out[(int64_t)fi * 12 + k] = (int32_t)word;
+    if (live && k == 12 && fi < cap) {
+      // createIndexVector's bin (matcher.cpp:208-212) and the (class, v) row of this
+      // feature: histogram + slot in one integer atomic; the arbitrary arrival
+      // order is undone by bin_sort
+      const int32_t uu = u * g.scale, vv = v * g.scale;
+      const int32_t b = (c * s.ubn + min(uu / s.binsize, s.ubn - 1)) * s.vbn + min(vv / s.binsize, s.vbn - 1);
+      const int32_t slot = atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
+      if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = fi;
+      atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], 1);
+    }
   }
 }
 
@@ -494,6 +529,12 @@ __global__ void planes_kernel(const uint8_t *__restrict__ I, int32_t bpl, int32_
 
 }  // namespace
 
+// rows start on 4-byte boundaries: enables the dword-load fast paths
+static bool images_dword_aligned(const VhImages &im, const VhGeom &g) {
+  return (g.bplm % 4 == 0) && (im.stride % 4 == 0) && ((uintptr_t)im.base[0] % 4 == 0) &&
+         (im.ncam < 2 || (uintptr_t)im.base[1] % 4 == 0);
+}
+
 void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipStream_t st) {
   dim3 grid((g.bplm + 255) / 256, g.Hm, src.S * src.ncam);
   hipLaunchKernelGGL(half_res_kernel, grid, dim3(256), 0, st, src, dst, g);
@@ -502,9 +543,7 @@ void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipS
 void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, int32_t *chunk_count,
                           hipStream_t st) {
   if (g.nblocks <= 0) return;
-  const bool aligned = (g.bplm % 4 == 0) && (im.stride % 4 == 0) && ((uintptr_t)im.base[0] % 4 == 0) &&
-                       (im.ncam < 2 || (uintptr_t)im.base[1] % 4 == 0);
-  if (aligned && g.n >= 1 && g.n <= 4) {
+  if (images_dword_aligned(im, g) && g.n >= 1 && g.n <= 4) {
     dim3 grid((g.nbx + 31) / 32, (g.nby + 7) / 8, im.S * im.ncam);
     switch (g.n) {
       case 1: hipLaunchKernelGGL(detect_nms_fast_kernel<1>, grid, dim3(256), 0, st, im, g, rec, chunk_count); break;
@@ -521,12 +560,13 @@ void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, in
 }
 
 void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t *rec,
-                             const int32_t *chunk_count, int32_t *feat, int32_t *count, int32_t cap,
-                             hipStream_t st) {
+                             const int32_t *chunk_count, const VhSets &s, hipStream_t st) {
   if (g.nblocks <= 0) return;
   dim3 grid(g.nchunks, im.S * im.ncam);
-  hipLaunchKernelGGL(emit_features_kernel, grid, dim3(256), 0, st, im, g, rec, chunk_count, feat, count,
-                     cap);
+  if (images_dword_aligned(im, g))
+    hipLaunchKernelGGL(emit_features_kernel<true>, grid, dim3(256), 0, st, im, g, rec, chunk_count, s);
+  else
+    hipLaunchKernelGGL(emit_features_kernel<false>, grid, dim3(256), 0, st, im, g, rec, chunk_count, s);
 }
 
 void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,

@@ -58,6 +58,7 @@ struct VhSets {
   int32_t *hist;
   int32_t *cursor;
   int32_t *tmp_idx;
+  int32_t *stage;      // [set][nbins][stage_cap] feature indices appended by emit_features (arbitrary order)
   int32_t *count;
   // row index (stereo search): the same records ordered by (class, v)
   int32_t *row_start;  // [set][4*H+1]
@@ -69,6 +70,7 @@ struct VhSets {
   int32_t *tile_cnt; // [set]
   int32_t cap, nbins, ubn, vbn, binsize, max_tiles;
   int32_t W, H;      // dims_c of the matcher (full resolution)
+  int32_t stage_cap;   // max features of one class in one bin for features of this detector (geometry bound)
   int32_t tile_span; // bins per tile group: vbn (one (class,u-bin) column) or ubn*vbn (a whole class)
 };
 
@@ -117,15 +119,14 @@ void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipS
 void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, int32_t *chunk_count,
                           hipStream_t st);
 void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t *rec,
-                             const int32_t *chunk_count, int32_t *feat, int32_t *count, int32_t cap,
-                             hipStream_t st);
+                             const int32_t *chunk_count, const VhSets &s, hipStream_t st);
 void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
                       int16_t *f1, int16_t *f2, hipStream_t st);
 
 void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
 void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
 void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
-void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
+void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, int32_t staged, hipStream_t st);
 void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, int32_t *list_ref,
                          hipStream_t st);
 

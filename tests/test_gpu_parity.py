@@ -70,6 +70,19 @@ def test_known_answers_full_size(case, pkg, oracle, gpu):
     assert pm[:32].tobytes() == z[case + "__head_p_match"].tobytes()
 
 
+def test_unaligned_stride_generic_kernels(pkg, ob, oracle, gpu):
+    """Rows that do not start on 4-byte boundaries (bpl = odd width, as the
+    reference's dims[2] >= dims[0] contract allows) take the byte-load kernels."""
+    rng = np.random.default_rng(3)
+    for W, H, n in ((201, 100, 2), (333, 121, 3), (255, 97, 6)):
+        img = pkg.synth.frame(W, H, blur=3, seed=W)[:, :W].copy()  # stride == W
+        dims = [W, H, W]
+        p, po = pkg.Params.default(nms_n=n), ob.Params.default(nms_n=n)
+        got = pkg.compute_features(p, img, dims)
+        want = oracle.compute_features(po, img, dims)
+        assert len(want[1]) > 100 and np.array_equal(got[1], want[1])
+
+
 # ------------------------------------------------ random parameter sweep vs the oracle
 @pytest.mark.parametrize("trial", range(8))
 def test_random_configs_vs_oracle(trial, pkg, ob, oracle, gpu):
