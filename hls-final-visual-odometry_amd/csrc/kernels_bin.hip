@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
       // irrelevant (the matcher minimises a (cost, bin position) key)
       const int32_t row = (int32_t)h.w * s.H + (int32_t)h.y;
       const int32_t rp = rs[row] + atomicAdd(&rcur[row], 1);
-      rmeta[rp] = make_uint2(h.x, (uint32_t)p);
+      rmeta[rp] = make_uint2((uint32_t)h.x | ((uint32_t)h.y << 16), (uint32_t)p);
       rdesc[2 * (int64_t)rp] = d0;
       rdesc[2 * (int64_t)rp + 1] = d1;
     }

@@ -202,17 +202,28 @@ template <int N> struct DetTile {
   static constexpr int ROWS = (FH + NSEG - 1) / NSEG;
 };
 
+template <int N, bool IS_MIN> __device__ __forceinline__ int32_t fold_window(const int32_t (&w)[2 * N + 1]) {
+  int32_t r = w[0];
+#pragma unroll
+  for (int32_t k = 1; k + 1 < 2 * N + 1; k += 2) r = IS_MIN ? min(r, min(w[k], w[k + 1])) : max(r, max(w[k], w[k + 1]));
+  return r;  // 2N+1 is odd: pairs (1,2),(3,4),... cover everything after w[0]
+}
+
 template <int N>
 __global__ void __launch_bounds__(256)
 detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__restrict__ chunk_count) {
   using T = DetTile<N>;
-  constexpr int N1 = T::N1;
-  __shared__ __attribute__((aligned(16))) uint8_t sI[T::IH * T::IP];
+  constexpr int N1 = T::N1, WN = 2 * N + 1;
+  constexpr int VH_ROWS = T::FH - 2 * N;                       // rows that can hold a block extremum
+  constexpr int NSEGV = (256 / T::FW) > 0 ? (256 / T::FW) : 1;
+  constexpr int ROWSV = (VH_ROWS + NSEGV - 1) / NSEGV;
+  constexpr int X_BYTES = (T::IH * T::IP > 4 * VH_ROWS * T::FP) ? T::IH * T::IP : 4 * VH_ROWS * T::FP;
   __shared__ __attribute__((aligned(16))) int16_t sF1[T::FH * T::FP];
   __shared__ __attribute__((aligned(16))) int16_t sF2[T::FH * T::FP];
-  __shared__ uint32_t sWork[4 * 256];
-  __shared__ uint16_t sCode[4 * 256];
-  __shared__ int32_t sCnt;
+  // scratch: first the staged image tile, later the window-min / window-max planes
+  __shared__ __attribute__((aligned(16))) uint8_t sX[X_BYTES];
+  uint8_t *sI = sX;
+  int16_t *sVmin = (int16_t *)sX, *sVmax = sVmin + VH_ROWS * T::FP;
 
   const int32_t id = blockIdx.z, tid = threadIdx.x;
   const uint8_t *__restrict__ I = vh_image_ptr(im, id);
@@ -222,7 +233,6 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   const int32_t ax0 = ix0 & ~3, off = ix0 & 3;
 
   // 1. stage the image tile with aligned dword loads (zero outside the image)
-  if (tid == 0) sCnt = 0;
   for (int32_t k = tid; k < T::IH * T::DW; k += 256) {
     const int32_t r = k / T::DW, c = k - r * T::DW;
     const int32_t gy = iy0 + r, gx = ax0 + 4 * c;
@@ -230,8 +240,6 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
     if (gy < g.Hm && gx < g.bplm) v = *(const uint32_t *)(I + (int64_t)gy * g.bplm + gx);
     ((uint32_t *)sI)[k] = v;
   }
-#pragma unroll
-  for (int32_t k = 0; k < 4; k++) sCode[tid * 4 + k] = VH_NO_CODE;
   __syncthreads();
 
   // 2. blob / checkerboard responses: one column per lane, sliding 5-row window
@@ -261,71 +269,90 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
       }
     }
   }
-  __syncthreads();
+  __syncthreads();  // responses complete; the image tile is dead from here on
 
-  // 3a. block extrema + threshold, one lane per NMS block (matcher.cpp:384-417,
-  //     threshold :427,:439,:451,:463); survivors go to the work list
+  // 3. NMS (Neubeck/Van Gool alg. 4, matcher.cpp:381-466).  The dominance test
+  //    "no strictly smaller value in the (2n+1)^2 window outside the block"
+  //    (matcher.cpp:420-426) is, because the candidate is already the minimum of
+  //    its own block, the same as "the candidate equals the minimum of the whole
+  //    window".  The window is clipped at W-1-margin / H-1-margin on the high
+  //    side only, which row/column replication reproduces.  So: (a) vertical
+  //    (2n+1)-row min/max of the response plane into LDS, (b) per block: extrema
+  //    (first in scan order, matcher.cpp:393-417), threshold, and a (2n+1)-wide
+  //    horizontal min/max over the vertical one.  Done for f1 then f2 through
+  //    the same scratch planes.
+  const int32_t xlim = min(max((g.Wm - 1 - VH_MARGIN) - fx0, 0), T::FW - 1);
+  const int32_t ylim = min(max((g.Hm - 1 - VH_MARGIN) - fy0, 0), T::FH - 1);
   const int32_t lby = tid / T::TBX, lbx = tid % T::TBX;
   const int32_t bx = bx0 + lbx, by = by0 + lby;
   const bool have_block = bx < g.nbx && by < g.nby;
   const int32_t fx = N + lbx * N1, fy = N + lby * N1;
-  if (have_block) {
-    const int16_t *b1 = sF1 + fy * T::FP + fx, *b2 = sF2 + fy * T::FP + fx;
-    int32_t v1n = b1[0], v1x = v1n, v2n = b2[0], v2x = v2n, p1n = 0, p1x = 0, p2n = 0, p2x = 0;
+  uint32_t codes[4];
 #pragma unroll
-    for (int32_t j = 0; j < N1; j++) {
+  for (int32_t plane = 0; plane < 2; plane++) {
+    const int16_t *F = plane ? sF2 : sF1;
+    // (a) vertical window extrema, one column per lane, sliding down the rows
+    for (int32_t task = tid; task < T::FW * NSEGV; task += 256) {
+      const int32_t seg = task / T::FW, cx = task - seg * T::FW;
+      const int32_t a = N + seg * ROWSV;  // first output row of this segment
+      int32_t w[WN];
 #pragma unroll
-      for (int32_t i = 0; i < N1; i++) {
-        const int32_t k = j * N1 + i;
-        int32_t cur = b1[j * T::FP + i];
-        if (cur < v1n) { v1n = cur; p1n = k; } else if (cur > v1x) { v1x = cur; p1x = k; }  // first extremum wins
-        cur = b2[j * T::FP + i];
-        if (cur < v2n) { v2n = cur; p2n = k; } else if (cur > v2x) { v2x = cur; p2x = k; }
+      for (int32_t k = 0; k < WN - 1; k++) w[k + 1] = F[min(a - N + k, ylim) * T::FP + cx];
+#pragma unroll
+      for (int32_t i = 0; i < ROWSV; i++) {
+        const int32_t r = a + i;
+        if (r < T::FH - N) {
+#pragma unroll
+          for (int32_t k = 0; k < WN - 1; k++) w[k] = w[k + 1];
+          w[WN - 1] = F[min(r + N, ylim) * T::FP + cx];
+          sVmin[(r - N) * T::FP + cx] = (int16_t)fold_window<N, true>(w);
+          sVmax[(r - N) * T::FP + cx] = (int16_t)fold_window<N, false>(w);
+        }
       }
     }
-    if (v1n <= -g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (0u << 8) | ((uint32_t)p1n << 10);
-    if (v1x >= g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (1u << 8) | ((uint32_t)p1x << 10);
-    if (v2n <= -g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (2u << 8) | ((uint32_t)p2n << 10);
-    if (v2x >= g.tau) sWork[atomicAdd(&sCnt, 1)] = (uint32_t)tid | (3u << 8) | ((uint32_t)p2x << 10);
-  }
-  __syncthreads();
-
-  // 3b. dominance test over the (2N+1)^2 window, clipped at W-1-margin /
-  //     H-1-margin, ignoring the candidate's own block (matcher.cpp:420-426)
-  const int32_t nwork = sCnt;
-  const int32_t xlim = (g.Wm - 1 - VH_MARGIN) - fx0, ylim = (g.Hm - 1 - VH_MARGIN) - fy0;
-  for (int32_t w = tid; w < nwork; w += 256) {
-    const uint32_t e = sWork[w];
-    const int32_t owner = e & 255, c = (e >> 8) & 3, pos = e >> 10;
-    const int32_t dy = pos / N1, dx = pos - dy * N1;
-    const int32_t ofx = N + (owner % T::TBX) * N1, ofy = N + (owner / T::TBX) * N1;
-    const int32_t cx = ofx + dx, cy = ofy + dy;
-    const int16_t *F = ((c < 2) ? sF1 : sF2) + cy * T::FP + cx;
-    const int32_t sgn = (c & 1) ? -1 : 1;  // maxima are tested as minima of the negated response
-    const int32_t val = sgn * (int32_t)F[0];
-    bool fail = false;
+    __syncthreads();
+    // (b) one lane per NMS block
+    uint32_t cmin = VH_NO_CODE, cmax = VH_NO_CODE;
+    if (have_block) {
+      const int16_t *b = F + fy * T::FP + fx;
+      int32_t vn = b[0], vx = vn, pn = 0, px = 0;
 #pragma unroll
-    for (int32_t j = -N; j <= N; j++) {
-      const bool row_in = (uint32_t)(dy + j) <= (uint32_t)N, row_ok = cy + j <= ylim;
+      for (int32_t j = 0; j < N1; j++) {
 #pragma unroll
-      for (int32_t i = -N; i <= N; i++) {
-        const bool col_in = (uint32_t)(dx + i) <= (uint32_t)N;
-        const int32_t cur = sgn * (int32_t)F[j * T::FP + i];
-        fail |= row_ok & (cx + i <= xlim) & !(row_in & col_in) & (cur < val);
+        for (int32_t i = 0; i < N1; i++) {
+          const int32_t cur = b[j * T::FP + i];
+          if (cur < vn) { vn = cur; pn = j * N1 + i; } else if (cur > vx) { vx = cur; px = j * N1 + i; }  // first extremum wins
+        }
+      }
+      if (vn <= -g.tau) {  // threshold (matcher.cpp:427,451)
+        const int32_t dy = pn / N1, dx = pn - dy * N1;
+        const int16_t *v = sVmin + (fy + dy - N) * T::FP;
+        int32_t m = v[min(fx + dx - N, xlim)];
+#pragma unroll
+        for (int32_t k = -N + 1; k <= N; k++) m = min(m, (int32_t)v[min(fx + dx + k, xlim)]);
+        if (m >= vn) cmin = (uint32_t)pn;
+      }
+      if (vx >= g.tau) {  // (matcher.cpp:439,463)
+        const int32_t dy = px / N1, dx = px - dy * N1;
+        const int16_t *v = sVmax + (fy + dy - N) * T::FP;
+        int32_t m = v[min(fx + dx - N, xlim)];
+#pragma unroll
+        for (int32_t k = -N + 1; k <= N; k++) m = max(m, (int32_t)v[min(fx + dx + k, xlim)]);
+        if (m <= vx) cmax = (uint32_t)px;
       }
     }
-    if (!fail) sCode[owner * 4 + c] = (uint16_t)pos;
+    codes[2 * plane] = cmin;
+    codes[2 * plane + 1] = cmax;
+    if (plane == 0) __syncthreads();  // scratch planes are rewritten for f2
   }
-  __syncthreads();
 
   // 4. 8 bytes per block + the per-chunk survivor count
   if (have_block) {
-    const uint2 cw = *(const uint2 *)(sCode + tid * 4);
     int32_t cnt = 0;
 #pragma unroll
-    for (int32_t c = 0; c < 4; c++) cnt += sCode[tid * 4 + c] != VH_NO_CODE ? 1 : 0;
+    for (int32_t c = 0; c < 4; c++) cnt += codes[c] != VH_NO_CODE ? 1 : 0;
     const int32_t blk = by * g.nbx + bx;
-    rec[(int64_t)id * g.nblocks + blk] = (uint64_t)cw.x | ((uint64_t)cw.y << 32);
+    rec[(int64_t)id * g.nblocks + blk] = (uint64_t)(codes[0] | (codes[1] << 16)) | ((uint64_t)(codes[2] | (codes[3] << 16)) << 32);
     if (cnt) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + blk / VH_CHUNK], cnt);
   }
 }

@@ -182,64 +182,90 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
 // The 1-d stereo search (v window of +-match_disp_tolerance, stock libviso2;
 // SURVEY App. A.7) accepts only a few dozen candidates per query, all within a
 // handful of image rows, so walking whole 50x50 bins would waste >95 % of the
-// work.  Here each lane walks its OWN candidates: the (class, v) row index makes
-// rows v1-tol..v1+tol one contiguous range, the lane tests |u2-u1| <= radius
-// and reduces with the same (SAD<<19 | bin position) key, which makes the
-// visiting order irrelevant -- the result equals findMatch's first minimum in
-// (u_bin, v_bin, list) order.
+// work.  Same lane-per-query / wave-uniform-stream scheme as the flow search,
+// but over the (class, v) ROW index on both sides: a tile is 64 consecutive
+// row-ordered queries of one class (they span only a few rows), and the
+// candidate stream is the single contiguous row range [vmin-tol, vmax+tol] of
+// the candidate set.  The key still carries the candidate's BIN-order position,
+// so the minimum is findMatch's first minimum in (u_bin, v_bin, list) order no
+// matter in which order the rows are walked.
 __global__ void __launch_bounds__(256)
-match_stereo_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
-  // 16 lanes per query: the lanes of a group take consecutive candidates of the
-  // query's row range, so a group's loads are contiguous (a per-lane walk would
-  // gather 64 unrelated cache lines per load instruction), then min-reduce the key.
+match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
+  __shared__ uint4 sDesc[4 * 128];
+  __shared__ uint2 sMeta[4 * 64];
   const int32_t pass = blockIdx.y, stream = blockIdx.z;
+  const int32_t lane = threadIdx.x & 63;
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
-  const int32_t nq = min(s.count[qset], s.cap);
-  const int32_t sub = threadIdx.x & 15;
-  // the loop bound is uniform per 16-lane group; whole groups retire together
-  for (int32_t q = (blockIdx.x * 256 + threadIdx.x) >> 4; q < ((nq + 3) & ~3); q += gridDim.x * 16) {
-  const bool live = q < nq;
-  const int32_t ql = live ? q : 0;
-  // dead groups (q >= nq) must not follow indices read from never-written memory
-  const int32_t orig = live ? s.s_idx[(int64_t)qset * s.cap + ql] : 0;
-  const uint32_t uv1 = live ? s.s_uv[(int64_t)qset * s.cap + ql] : 0;
-  const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
-  const uint4 a0 = qdesc[2 * (int64_t)ql], a1 = qdesc[2 * (int64_t)ql + 1];
-  // class of a bin-ordered position: bins are class-major
-  const int32_t *__restrict__ qbs = s.bin_start + (int64_t)qset * (s.nbins + 1);
-  const int32_t per_class = s.ubn * s.vbn;
-  const int32_t c = (ql >= qbs[per_class] ? 1 : 0) + (ql >= qbs[2 * per_class] ? 1 : 0) + (ql >= qbs[3 * per_class] ? 1 : 0);
-  const int32_t u1 = uv1 & 0xFFFF, v1 = uv1 >> 16;
-  const int32_t v_lo = max(v1 - a.disp_tol, 0), v_hi = min(v1 + a.disp_tol, s.H - 1);
-  const int32_t *__restrict__ crs = s.row_start + (int64_t)cset * (4 * s.H + 1) + c * s.H;
-  const uint2 *__restrict__ rmeta = s.r_meta + (int64_t)cset * s.cap;
-  const uint4 *__restrict__ rdesc = (const uint4 *)(s.r_desc + (int64_t)cset * s.cap * 8);
-  const int32_t r0 = live ? crs[v_lo] : 0, r1 = live ? crs[v_hi + 1] : 0;
-  uint32_t best_key = 0xFFFFFFFFu;
-  for (int32_t r = r0 + sub; r < r1; r += 16) {
-    const uint2 meta = rmeta[r];
-    const uint4 b0 = rdesc[2 * (int64_t)r], b1 = rdesc[2 * (int64_t)r + 1];
-    const int32_t du = (int32_t)meta.x - u1;
-    const bool in = (du >= -a.radius) & (du <= a.radius);  // matcher.cpp:249 (v holds by construction)
-    uint32_t sad = sad4(a0.x, b0.x, 0);
-    sad = sad4(a0.y, b0.y, sad);
-    sad = sad4(a0.z, b0.z, sad);
-    sad = sad4(a0.w, b0.w, sad);
-    sad = sad4(a1.x, b1.x, sad);
-    sad = sad4(a1.y, b1.y, sad);
-    sad = sad4(a1.z, b1.z, sad);
-    sad = sad4(a1.w, b1.w, sad);
-    best_key = min(best_key, in ? ((sad << 19) | meta.y) : 0xFFFFFFFFu);
-  }
+  const int32_t nrow = 4 * s.H;
+  const int32_t *__restrict__ qrs = s.row_start + (int64_t)qset * (nrow + 1);
+  const int32_t *__restrict__ crs = s.row_start + (int64_t)cset * (nrow + 1);
+  const uint2 *__restrict__ qmeta = s.r_meta + (int64_t)qset * s.cap;
+  const uint4 *__restrict__ qdesc = (const uint4 *)(s.r_desc + (int64_t)qset * s.cap * 8);
+  const uint2 *__restrict__ cmeta = s.r_meta + (int64_t)cset * s.cap;
+  const uint4 *__restrict__ cdesc = (const uint4 *)(s.r_desc + (int64_t)cset * s.cap * 8);
+  const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
+  const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
+  // tile -> (class, query range): classes are contiguous in row order
+  int32_t cls_q0[5];
 #pragma unroll
-  for (int32_t d = 8; d >= 1; d >>= 1) best_key = min(best_key, (uint32_t)__shfl_xor((int32_t)best_key, d));
-  if (live && sub == 0) {
-    // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-    const int32_t res = (best_key == 0xFFFFFFFFu) ? 0 : s.s_idx[(int64_t)cset * s.cap + (best_key & 0x7FFFFu)];
-    best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + orig] = res;
+  for (int32_t c = 0; c <= 4; c++) cls_q0[c] = __builtin_amdgcn_readfirstlane(qrs[c * s.H]);
+  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
+  uint2 *wM = sMeta + (threadIdx.x >> 6) * 64;
+  for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));; tile += gridDim.x * 4) {
+    int32_t c = -1, q0 = 0, q1 = 0, t = tile;
+#pragma unroll
+    for (int32_t k = 0; k < 4; k++) {
+      const int32_t nt = (cls_q0[k + 1] - cls_q0[k] + 63) >> 6;
+      if (c < 0 && t < nt) { c = k; q0 = cls_q0[k] + 64 * t; q1 = min(cls_q0[k + 1], q0 + 64); }
+      if (c < 0) t -= nt;
+    }
+    if (c < 0) break;  // past the last tile (uniform)
+    const int32_t q = q0 + lane;
+    const bool valid = q < q1;
+    const int32_t ql = valid ? q : q0;
+    const uint2 qm = qmeta[ql];
+    const uint4 a0 = qdesc[2 * (int64_t)ql], a1 = qdesc[2 * (int64_t)ql + 1];
+    const int32_t u1 = qm.x & 0xFFFF, v1 = qm.x >> 16;
+    // window: u1 +- radius, v1 +- disp_tolerance; packed accept test as in the flow search
+    const us2 lo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
+    const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * a.disp_tol)};
+    const int32_t VLO = max(__builtin_amdgcn_readfirstlane(wave_min(valid ? v1 : 0x7FFFFFFF)) - a.disp_tol, 0);
+    const int32_t VHI = min(__builtin_amdgcn_readfirstlane(wave_max(valid ? v1 : -1)) + a.disp_tol, s.H - 1);
+    const int32_t r0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VLO]);
+    const int32_t r1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VHI + 1]);
+    uint32_t best_key = 0xFFFFFFFFu;
+    for (int32_t rc = r0; rc < r1; rc += 64) {
+      const int32_t mcnt = min(64, r1 - rc);
+      const int32_t rl = min(rc + lane, r1 - 1);
+      const uint2 gm = cmeta[rl];
+      const uint4 g0 = cdesc[2 * (int64_t)rl], g1 = cdesc[2 * (int64_t)rl + 1];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
+      wM[lane] = gm; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
+      for (int32_t j = 0; j < mcnt; j++) {
+        const uint2 cm = wM[j];
+        const uint4 b0 = wD[2 * j], b1 = wD[2 * j + 1];
+        const us2 tt = as_us2(cm.x) - lo2;
+        const us2 mm = __builtin_elementwise_min(tt, span2);
+        const bool out = as_u32(tt) != as_u32(mm);
+        uint32_t sad = sad4(a0.x, b0.x, 0);
+        sad = sad4(a0.y, b0.y, sad);
+        sad = sad4(a0.z, b0.z, sad);
+        sad = sad4(a0.w, b0.w, sad);
+        sad = sad4(a1.x, b1.x, sad);
+        sad = sad4(a1.y, b1.y, sad);
+        sad = sad4(a1.z, b1.z, sad);
+        sad = sad4(a1.w, b1.w, sad);
+        best_key = min(best_key, out ? 0xFFFFFFFFu : ((sad << 19) | cm.y));
+      }
+    }
+    if (valid) {
+      // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
+      const int32_t res = (best_key == 0xFFFFFFFFu) ? 0 : cidx[best_key & 0x7FFFFu];
+      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[qm.y]] = res;
+    }
   }
-  }  // query loop
 }
 
 // ---------------------------------------------------------------------- chain
@@ -385,8 +411,8 @@ static VhMatchArgs filter_passes(const VhMatchArgs &a, int32_t flow) {
 void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
   const VhMatchArgs sr = filter_passes(a, 0);
   if (!sr.npass) return;
-  dim3 grid(std::min(std::max(s.cap / 32, 64), 4096), sr.npass, a.S);  // 16 queries per workgroup per trip
-  hipLaunchKernelGGL(match_stereo_kernel, grid, dim3(256), 0, st, s, sr, best);
+  dim3 grid(std::min(std::max(s.cap / 1024, 8), 1024), sr.npass, a.S);  // 4 tiles of 64 queries per workgroup per trip
+  hipLaunchKernelGGL(match_rows_kernel, grid, dim3(256), 0, st, s, sr, best);
 }
 void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
   const VhMatchArgs fl = filter_passes(a, 1);
