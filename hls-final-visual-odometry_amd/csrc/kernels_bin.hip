@@ -138,12 +138,13 @@ __global__ void bin_fill_kernel(VhSets s, int32_t set0) {
   }
 }
 
-// One wave per bin: the atomic fill left the bin's members in arbitrary order;
-// rank-sort them back to ascending feature index (the reference's push_back
-// order) and gather the bin-ordered structure-of-arrays.
+// 16 lanes per bin (typical bins hold 5-20 features): the atomic fill left the
+// bin's members in arbitrary order; rank-sort them back to ascending feature
+// index (the reference's push_back order) and gather the bin-ordered
+// structure-of-arrays and the row-ordered copy.
 __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, int32_t staged) {
   const int32_t set = set0 + blockIdx.y;
-  const int32_t bin = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int32_t bin = blockIdx.x * 16 + (threadIdx.x >> 4), gl = threadIdx.x & 15;
   if (bin >= s.nbins) return;
   const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
   const int32_t p0 = bs[bin], p1 = bs[bin + 1], L = p1 - p0;
@@ -161,19 +162,22 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
   int32_t *__restrict__ rcur = s.row_cursor + (int64_t)set * nrow;
   uint2 *__restrict__ rmeta = s.r_meta + (int64_t)set * s.cap;
   uint4 *__restrict__ rdesc = (uint4 *)(s.r_desc + (int64_t)set * s.cap * 8);
-  for (int32_t e0 = 0; e0 < L; e0 += 64) {
-    const int32_t e = e0 + lane;
+  for (int32_t e0 = 0; e0 < L; e0 += 16) {
+    const int32_t e = e0 + gl;
     const int32_t mine = (e < L) ? tmp[p0 + e] : 0x7FFFFFFF;
+    uint4 h = make_uint4(0, 0, 0, 0), d0 = h, d1 = h;
+    if (e < L) {  // the record gather does not depend on the rank: issue it first
+      const int32_t *f = feat + (int64_t)mine * 12;
+      h = *(const uint4 *)f; d0 = *(const uint4 *)(f + 4); d1 = *(const uint4 *)(f + 8);
+    }
     int32_t rank = 0;
-    for (int32_t j0 = 0; j0 < L; j0 += 64) {
-      const int32_t other = (j0 + lane < L) ? tmp[p0 + j0 + lane] : 0x7FFFFFFF;
-      const int32_t m = min(64, L - j0);
-      for (int32_t j = 0; j < m; j++) rank += (__shfl(other, j) < mine) ? 1 : 0;
+    for (int32_t j0 = 0; j0 < L; j0 += 16) {
+      const int32_t other = (j0 + gl < L) ? tmp[p0 + j0 + gl] : 0x7FFFFFFF;
+      const int32_t m = min(16, L - j0);
+      for (int32_t j = 0; j < m; j++) rank += (__shfl(other, j, 16) < mine) ? 1 : 0;
     }
     if (e < L) {
       const int32_t p = p0 + rank;
-      const int32_t *f = feat + (int64_t)mine * 12;
-      const uint4 h = *(const uint4 *)f, d0 = *(const uint4 *)(f + 4), d1 = *(const uint4 *)(f + 8);
       sidx[p] = mine;
       suv[p] = (uint32_t)h.x | ((uint32_t)h.y << 16);
       sdesc[2 * (int64_t)p] = d0;
@@ -231,7 +235,7 @@ void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_
   hipLaunchKernelGGL(bin_fill_kernel, grid, dim3(256), 0, st, s, set0);
 }
 void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, int32_t staged, hipStream_t st) {
-  dim3 grid((s.nbins + 3) / 4, nsets);
+  dim3 grid((s.nbins + 15) / 16, nsets);
   hipLaunchKernelGGL(bin_sort_kernel, grid, dim3(256), 0, st, s, set0, staged);
 }
 void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, int32_t *list_ref,
