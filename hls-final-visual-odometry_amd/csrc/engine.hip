@@ -4,7 +4,7 @@
 // A vh_group owns S independent camera streams that are stepped together; a
 // vh_matcher is a group of one.  The reference's Matcher state (ring buffer of
 // two feature-set pairs, src/matcher.h:245-259) lives in HBM and rotates by
-// flipping `pair_cur`; nothing is copied on pushBack.
+// moving the current/previous roles between three slots; nothing is copied on pushBack.
 #include "vh_dev.h"
 #include "../../include/viso_hip.h"
 
@@ -41,7 +41,16 @@ struct Group {
   vh_params p{};
   int32_t device = 0, S = 1;
   int32_t req_features = 0, req_matches = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
+  // Two internal streams: detection+indexing of frame t+1 overlaps the matching
+  // of frame t (the ring has three slots for that).  `stream` is the detect
+  // stream (also used by the stateless paths); a caller-owned stream, if set,
+  // only orders our work after the caller's (image producers).
+  hipStream_t own_stream = nullptr, stream = nullptr, match_stream = nullptr, user_stream = nullptr;
+  hipEvent_t ev_det[3] = {nullptr, nullptr, nullptr};   // slot fully detected + indexed
+  hipEvent_t ev_read[3] = {nullptr, nullptr, nullptr};  // last match that read the slot
+  bool ev_read_valid[3] = {false, false, false};
+  hipEvent_t ev_user = nullptr;
+  int32_t pair_prev = 1;
 
   bool allocated = false;
   int32_t dims[3] = {0, 0, 0};
@@ -71,7 +80,19 @@ struct Group {
   bool prof = false;
   std::map<std::string, ProfEntry> prof_entries;
 
-  ~Group() { release(); if (own_stream) hipStreamDestroy(own_stream); }
+  ~Group() {
+    release();
+    for (int k = 0; k < 3; k++) { if (ev_det[k]) (void)hipEventDestroy(ev_det[k]); if (ev_read[k]) (void)hipEventDestroy(ev_read[k]); }
+    if (ev_user) (void)hipEventDestroy(ev_user);
+    if (match_stream) (void)hipStreamDestroy(match_stream);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+  int32_t pairs() const { return pair_cur | (pair_prev << 8); }
+  int32_t sync_all() {
+    VH_HIP(hipStreamSynchronize(stream));
+    VH_HIP(hipStreamSynchronize(match_stream));
+    return VH_OK;
+  }
 
   void release() {
     for (void *q : allocs) hipFree(q);
@@ -128,7 +149,7 @@ struct Group {
 
   int32_t ensure(const int32_t d[3]) {
     if (allocated && d[0] == dims[0] && d[1] == dims[1] && d[2] == dims[2]) return VH_OK;
-    if (allocated) { VH_HIP(hipStreamSynchronize(stream)); release(); }
+    if (allocated) { int32_t rs = sync_all(); if (rs) return rs; release(); }
     if (d[0] <= 0 || d[1] <= 0 || d[2] < d[0]) return VH_ERR_INVALID_ARG;
     if (d[0] > 16384 || d[1] > 16384) return VH_ERR_UNSUPPORTED;
     int32_t rc = setup_geometry(d);
@@ -153,7 +174,7 @@ struct Group {
       sets.stage_cap = (int32_t)std::min<int64_t>(per_axis * per_axis, cap);
     }
     sets.tile_span = (2 * p.match_radius >= dims[1]) ? sets.ubn * sets.vbn : sets.vbn;
-    const size_t ns = 4 * (size_t)S;
+    const size_t ns = 6 * (size_t)S;  // 3 ring slots x (left, right) per stream
     if ((rc = dmalloc(&sets.feat, ns * cap * 12, false))) return rc;
     if ((rc = dmalloc(&sets.s_uv, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.s_idx, ns * cap, false))) return rc;
@@ -181,18 +202,21 @@ struct Group {
     if (p.half_resolution)
       if ((rc = dmalloc(&d_half, 2 * (size_t)S * g.bplm * g.Hm, false))) return rc;
     allocated = true;
-    pair_cur = 0; frames = 0; epoch = 0; last_method = -1; bucketed = false;
+    pair_cur = 0; pair_prev = 1; frames = 0; epoch = 0; last_method = -1; bucketed = false;
+    for (int k = 0; k < 3; k++) ev_read_valid[k] = false;
+    // every slot starts "detected" (empty): matches may wait on any of them
+    for (int k = 0; k < 3; k++) VH_HIP(hipEventRecord(ev_det[k], stream));
     return VH_OK;
   }
 
   // ---- profiling ---------------------------------------------------------
   struct Scope {
-    Group *gq; const char *name; hipEvent_t e0 = nullptr, e1 = nullptr;
-    Scope(Group *gq_, const char *n) : gq(gq_), name(n) {
-      if (gq->prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, gq->stream); }
+    Group *gq; const char *name; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    Scope(Group *gq_, const char *n, hipStream_t st_) : gq(gq_), name(n), st(st_) {
+      if (gq->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
     }
     ~Scope() {
-      if (gq->prof) { hipEventRecord(e1, gq->stream); gq->prof_entries[name].pending.emplace_back(e0, e1); }
+      if (gq->prof) { (void)hipEventRecord(e1, st); gq->prof_entries[name].pending.emplace_back(e0, e1); }
     }
   };
   void prof_collect() {
@@ -224,11 +248,11 @@ struct Group {
     if (!staged) {
       int32_t rc = zero_bin_counters(set0, nsets);
       if (rc) return rc;
-      { Scope sc(this, "bin_hist"); vh_launch_bin_hist(sets, set0, nsets, stream); }
+      { Scope sc(this, "bin_hist", stream); vh_launch_bin_hist(sets, set0, nsets, stream); }
     }
-    { Scope sc(this, "bin_scan"); vh_launch_bin_scan(sets, set0, nsets, stream); }
-    if (!staged) { Scope sc(this, "bin_fill"); vh_launch_bin_fill(sets, set0, nsets, stream); }
-    { Scope sc(this, "bin_sort"); vh_launch_bin_sort(sets, set0, nsets, staged ? 1 : 0, stream); }
+    { Scope sc(this, "bin_scan", stream); vh_launch_bin_scan(sets, set0, nsets, stream); }
+    if (!staged) { Scope sc(this, "bin_fill", stream); vh_launch_bin_fill(sets, set0, nsets, stream); }
+    { Scope sc(this, "bin_sort", stream); vh_launch_bin_sort(sets, set0, nsets, staged ? 1 : 0, stream); }
     VH_HIP(hipGetLastError());
     return VH_OK;
   }
@@ -237,10 +261,21 @@ struct Group {
     if (!dI1 || !d) return VH_ERR_INVALID_ARG;
     int32_t rc = ensure(d);
     if (rc != VH_OK) return rc;
-    if (!replace && frames > 0) pair_cur ^= 1;  // ring buffer shift (matcher.cpp:64-79)
+    if (!replace && frames > 0) {  // ring buffer shift (matcher.cpp:64-79): prev <- cur, cur <- the third slot
+      const int32_t fresh = 3 - pair_cur - pair_prev;
+      pair_prev = pair_cur;
+      pair_cur = fresh;
+    }
     frames++;
     bucketed = false; last_method = -1;
     const int32_t set0 = pair_cur * 2 * S, nsets = 2 * S;
+    // order after the caller's stream (image producers) and after the last match
+    // that still reads the slot we are about to overwrite
+    if (user_stream) {
+      VH_HIP(hipEventRecord(ev_user, user_stream));
+      VH_HIP(hipStreamWaitEvent(stream, ev_user, 0));
+    }
+    if (ev_read_valid[pair_cur]) VH_HIP(hipStreamWaitEvent(stream, ev_read[pair_cur], 0));
     VH_HIP(hipMemsetAsync(sets.count + set0, 0, sizeof(int32_t) * nsets, stream));
     VH_HIP(hipMemsetAsync(d_chunk_count, 0, sizeof(int32_t) * 2 * (size_t)S * g.nchunks, stream));
     if ((rc = zero_bin_counters(set0, nsets))) return rc;
@@ -248,17 +283,19 @@ struct Group {
     im.base[0] = (const uint8_t *)dI1; im.base[1] = (const uint8_t *)dI2;
     im.stride = stride; im.ncam = dI2 ? 2 : 1; im.S = S; im.pair_cur = pair_cur;
     if (p.half_resolution) {
-      { Scope sc(this, "half_res"); vh_launch_half_res(im, d_half, g, stream); }
+      { Scope sc(this, "half_res", stream); vh_launch_half_res(im, d_half, g, stream); }
       // half images are stored by image id; present them as one "camera" with unit stride
       VhImages hm = im;
       const int64_t isz = (int64_t)g.bplm * g.Hm;
       hm.base[0] = d_half; hm.base[1] = d_half + isz; hm.stride = isz * im.ncam;
       im = hm;
     }
-    { Scope sc(this, "detect_nms"); vh_launch_detect_nms(im, g, d_rec, d_chunk_count, stream); }
-    { Scope sc(this, "emit_features"); vh_launch_emit_features(im, g, d_rec, d_chunk_count, sets, stream); }
+    { Scope sc(this, "detect_nms", stream); vh_launch_detect_nms(im, g, d_rec, d_chunk_count, stream); }
+    { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, d_rec, d_chunk_count, sets, stream); }
     VH_HIP(hipGetLastError());
-    return bin_sets(set0, nsets, true);
+    if ((rc = bin_sets(set0, nsets, true))) return rc;
+    VH_HIP(hipEventRecord(ev_det[pair_cur], stream));
+    return VH_OK;
   }
 
   int32_t push_host(const uint8_t *I1, const uint8_t *I2, int64_t stride, const int32_t d[3], int32_t replace) {
@@ -270,6 +307,7 @@ struct Group {
       for (int k = 0; k < 2; k++) if ((rc = dmalloc(&d_stage[k], isz * S, false))) return rc;
       stage_bytes = isz * S;
     }
+    VH_HIP(hipStreamSynchronize(stream));  // the previous frame's detection still reads the staging buffers
     for (int k = 0; k < 2; k++) {
       const uint8_t *src = k ? I2 : I1;
       if (!src) continue;
@@ -284,7 +322,7 @@ struct Group {
   // ---- match ---------------------------------------------------------------
   VhMatchArgs match_args(int32_t method) const {
     VhMatchArgs a{};
-    a.S = S; a.pair_cur = pair_cur; a.radius = p.match_radius; a.disp_tol = p.match_disp_tolerance;
+    a.S = S; a.pair_cur = pairs(); a.radius = p.match_radius; a.disp_tol = p.match_disp_tolerance;
     if (method == VH_METHOD_FLOW) {  // matcher.cpp:320-321
       a.npass = 2; a.pass[0] = {VH_SET_1C, VH_SET_1P, 1, 0}; a.pass[1] = {VH_SET_1P, VH_SET_1C, 1, 1};
     } else if (method == VH_METHOD_STEREO) {
@@ -301,18 +339,30 @@ struct Group {
     if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
     if (!allocated) return VH_ERR_STATE;
     const VhMatchArgs a = match_args(method);
+    hipStream_t ms = match_stream;
+    // the current slot's detection+indexing must be complete (the previous
+    // slot's finished earlier on the same stream)
+    VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_cur], 0));
+    VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_prev], 0));
     if (method == VH_METHOD_FLOW) {
-      if (!d_mask) { int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], true); if (rc) return rc; epoch = 0; }
+      if (!d_mask) {
+        int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) return rc;
+        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ms));
+        epoch = 0;
+      }
       if (++epoch >= 4095) {
-        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], stream));
+        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ms));
         epoch = 1;
       }
     }
-    { Scope sc(this, "match_stereo"); vh_launch_match_stereo(sets, a, d_best, stream); }
-    { Scope sc(this, "match_flow"); vh_launch_match_flow(sets, a, d_best, stream); }
-    { Scope sc(this, "chain"); vh_launch_chain(sets, a, method, d_best, d_chain, d_mask, epoch, stream); }
-    { Scope sc(this, "emit_matches"); vh_launch_emit_matches(sets, a, method, d_chain, d_mask, epoch, d_matches, mcap, d_match_count, stream); }
+    { Scope sc(this, "match_stereo", ms); vh_launch_match_stereo(sets, a, d_best, ms); }
+    { Scope sc(this, "match_flow", ms); vh_launch_match_flow(sets, a, d_best, ms); }
+    { Scope sc(this, "chain", ms); vh_launch_chain(sets, a, method, d_best, d_chain, d_mask, epoch, ms); }
+    { Scope sc(this, "emit_matches", ms); vh_launch_emit_matches(sets, a, method, d_chain, d_mask, epoch, d_matches, mcap, d_match_count, ms); }
     VH_HIP(hipGetLastError());
+    // both slots stay in use until this point of the match stream
+    VH_HIP(hipEventRecord(ev_read[pair_cur], ms)); ev_read_valid[pair_cur] = true;
+    VH_HIP(hipEventRecord(ev_read[pair_prev], ms)); ev_read_valid[pair_prev] = true;
     last_method = method; bucketed = false;
     return VH_OK;
   }
@@ -328,14 +378,14 @@ struct Group {
       return *n > capo ? VH_ERR_CAPACITY : VH_OK;
     }
     int32_t cnt = 0;
-    VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    VH_HIP(hipStreamSynchronize(stream));
+    VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, match_stream));
+    VH_HIP(hipStreamSynchronize(match_stream));
     *n = cnt;
     const int32_t k = std::min(std::min(cnt, mcap), capo);
     if (k > 0) {
       VH_HIP(hipMemcpyAsync(out, (const uint8_t *)d_matches + (size_t)s * mcap * sizeof(vh_p_match),
-                            sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, stream));
-      VH_HIP(hipStreamSynchronize(stream));
+                            sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, match_stream));
+      VH_HIP(hipStreamSynchronize(match_stream));
     }
     return (cnt > capo || cnt > mcap) ? VH_ERR_CAPACITY : VH_OK;
   }
@@ -344,7 +394,7 @@ struct Group {
     if (!n || s < 0 || s >= S || which < 0 || which > 3 || capo < 0 || (capo > 0 && !out12)) return VH_ERR_INVALID_ARG;
     *n = 0;
     if (!allocated) return VH_OK;
-    const int32_t set = vh_role_set(S, pair_cur, s, which);
+    const int32_t set = vh_role_set(S, pairs(), s, which);
     int32_t cnt = 0;
     VH_HIP(hipMemcpyAsync(&cnt, sets.count + set, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     VH_HIP(hipStreamSynchronize(stream));
@@ -361,15 +411,15 @@ struct Group {
   int32_t get_counts(int32_t *nf, int32_t *nm) {
     if (!allocated) return VH_ERR_STATE;
     if (nf) {
-      std::vector<int32_t> all(4 * (size_t)S);
+      std::vector<int32_t> all(6 * (size_t)S);
       VH_HIP(hipMemcpyAsync(all.data(), sets.count, sizeof(int32_t) * all.size(), hipMemcpyDeviceToHost, stream));
       VH_HIP(hipStreamSynchronize(stream));
       for (int32_t s = 0; s < S; s++)
-        for (int32_t r = 0; r < 4; r++) nf[4 * s + r] = all[vh_role_set(S, pair_cur, s, r)];
+        for (int32_t r = 0; r < 4; r++) nf[4 * s + r] = all[vh_role_set(S, pairs(), s, r)];
     }
     if (nm) {
-      VH_HIP(hipMemcpyAsync(nm, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, stream));
-      VH_HIP(hipStreamSynchronize(stream));
+      VH_HIP(hipMemcpyAsync(nm, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, match_stream));
+      VH_HIP(hipStreamSynchronize(match_stream));
     }
     return VH_OK;
   }
@@ -382,11 +432,16 @@ struct Group {
       const int32_t *f = m + 12 * (size_t)i;
       if (f[0] < 0 || f[0] >= dims[0] || f[1] < 0 || f[1] >= dims[1] || f[3] < 0 || f[3] > 3) return VH_ERR_INVALID_ARG;
     }
-    const int32_t set = vh_role_set(S, pair_cur, 0, role);
+    const int32_t set = vh_role_set(S, pairs(), 0, role);
+    const int32_t slot = (role >= 2) ? pair_cur : pair_prev;
+    if (ev_read_valid[slot]) VH_HIP(hipStreamWaitEvent(stream, ev_read[slot], 0));
     if (n) VH_HIP(hipMemcpyAsync(sets.feat + (size_t)set * cap * 12, m, sizeof(int32_t) * 12 * (size_t)n, hipMemcpyHostToDevice, stream));
     VH_HIP(hipMemcpyAsync(sets.count + set, &n, sizeof(int32_t), hipMemcpyHostToDevice, stream));
     VH_HIP(hipStreamSynchronize(stream));
-    return bin_sets(set, 1, false);
+    int32_t rc = bin_sets(set, 1, false);
+    if (rc) return rc;
+    VH_HIP(hipEventRecord(ev_det[slot], stream));
+    return VH_OK;
   }
 };
 
@@ -457,6 +512,12 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
     return VH_ERR_HIP;
   }
   gq->stream = gq->own_stream;
+  bool ok = hipStreamCreateWithFlags(&gq->match_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int k = 0; k < 3 && ok; k++)
+    ok = hipEventCreateWithFlags(&gq->ev_det[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&gq->ev_read[k], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&gq->ev_user, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { t_last_error = "stream/event creation failed"; delete gq; return VH_ERR_HIP; }
   *out = gq;
   return VH_OK;
 }
@@ -468,7 +529,7 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
 
 struct Temp {  // transient one-stream group for the stateless entry points
   Group *gq = nullptr;
-  ~Temp() { if (gq) { hipStreamSynchronize(gq->stream); delete gq; } }
+  ~Temp() { if (gq) { (void)gq->sync_all(); delete gq; } }
 };
 
 }  // namespace
@@ -515,8 +576,8 @@ int32_t vh_group_create(const vh_params *p, int32_t device, int32_t n_streams, i
 void vh_group_destroy(vh_group *g) {
   if (!g) return;
   Group *gq = (Group *)g;
-  hipSetDevice(gq->device);
-  hipStreamSynchronize(gq->stream);
+  (void)hipSetDevice(gq->device);
+  (void)gq->sync_all();
   gq->prof_collect();
   delete gq;
 }
@@ -549,13 +610,13 @@ int32_t vh_group_get_counts(vh_group *g, int32_t *n_features, int32_t *n_matches
 }
 int32_t vh_group_synchronize(vh_group *g) {
   Group *gq = (Group *)g; ENTER(gq);
-  VH_HIP(hipStreamSynchronize(gq->stream));
-  return VH_OK;
+  return gq->sync_all();
 }
 int32_t vh_group_set_stream(vh_group *g, void *hip_stream) {
   Group *gq = (Group *)g; ENTER(gq);
-  VH_HIP(hipStreamSynchronize(gq->stream));
-  gq->stream = hip_stream ? (hipStream_t)hip_stream : gq->own_stream;
+  int32_t rc = gq->sync_all();
+  if (rc) return rc;
+  gq->user_stream = (hipStream_t)hip_stream;  // NULL: no external ordering
   return VH_OK;
 }
 int32_t vh_group_profile_enable(vh_group *g, int32_t on) {
@@ -713,7 +774,7 @@ int32_t vh_create_index(const vh_params *p, int32_t device, const int32_t dims[3
   int32_t *d_bs = nullptr, *d_list = nullptr;
   if ((rc = gq->dmalloc(&d_bs, (size_t)gq->sets.nbins + 1, false))) return rc;
   if ((rc = gq->dmalloc(&d_list, (size_t)std::max(n, 1), false))) return rc;
-  vh_launch_ref_index(gq->sets, vh_role_set(1, gq->pair_cur, 0, VH_SET_1C), d_bs, d_list, gq->stream);
+  vh_launch_ref_index(gq->sets, vh_role_set(1, gq->pairs(), 0, VH_SET_1C), d_bs, d_list, gq->stream);
   VH_HIP(hipMemcpyAsync(bin_start, d_bs, sizeof(int32_t) * ((size_t)gq->sets.nbins + 1), hipMemcpyDeviceToHost, gq->stream));
   if (n) VH_HIP(hipMemcpyAsync(list, d_list, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, gq->stream));
   VH_HIP(hipStreamSynchronize(gq->stream));

@@ -5,9 +5,10 @@
 // stream of a group):
 //
 //   image id  = stream*2 + cam                      (cam 0 = left, 1 = right)
-//   set id    = pair*(2*S) + stream*2 + cam         (pair = ring slot 0/1; the
-//               current/previous roles swap by flipping `pair`, never by copy:
-//               reference ring buffer src/matcher.cpp:64-79)
+//   set id    = pair*(2*S) + stream*2 + cam         (pair = ring slot 0..2; the
+//               current/previous roles move from slot to slot, never by copy:
+//               reference ring buffer src/matcher.cpp:64-79.  Three slots, so
+//               that detection of frame t+1 can run while frame t is matched)
 //
 //   feat      [set][cap][12] int32   the reference's packed record
 //                                    {u,v,0,c,d1..d8} (src/matcher.cpp:663-671)
@@ -84,7 +85,7 @@ struct VhPass {
 struct VhMatchArgs {
   VhPass pass[4];
   int32_t npass;
-  int32_t pair_cur;  // ring slot holding the current frame
+  int32_t pair_cur;  // ring slots: current frame | previous frame << 8
   int32_t S;
   int32_t radius, disp_tol;
 };
@@ -93,8 +94,8 @@ __host__ __device__ inline int32_t vh_set_id(int32_t S, int32_t pair, int32_t st
   return pair * (2 * S) + stream * 2 + cam;
 }
 // role: 0=1p 1=2p 2=1c 3=2c
-__host__ __device__ inline int32_t vh_role_set(int32_t S, int32_t pair_cur, int32_t stream, int32_t role) {
-  const int32_t pair = (role >= 2) ? pair_cur : (pair_cur ^ 1);
+__host__ __device__ inline int32_t vh_role_set(int32_t S, int32_t pairs, int32_t stream, int32_t role) {
+  const int32_t pair = (role >= 2) ? (pairs & 0xFF) : (pairs >> 8);
   return vh_set_id(S, pair, stream, role & 1);
 }
 
