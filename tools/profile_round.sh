@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): rocprofv3 evidence for one round.
+#   tools/profile_round.sh <tag>      ->  gpurun_out/prof_<tag>/{stats,fetch,write}/...
+# --kernel-trace/--stats and the PMC passes are separate runs (the pool refuses
+# mixing them); FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots).
+set -e
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --no-cpu > $OUT/bench_stats.log 2>&1
+tail -1 $OUT/bench_stats.log | cut -c1-300
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --no-cpu --steps 6 --warmup 2 > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --no-cpu --steps 6 --warmup 2 > $OUT/bench_write.log 2>&1
+python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+tail -c 600 $OUT/bench_plain.json
