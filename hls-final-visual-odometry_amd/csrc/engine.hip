@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -45,12 +46,21 @@ struct Group {
   // of frame t (the ring has three slots for that).  `stream` is the detect
   // stream (also used by the stateless paths); a caller-owned stream, if set,
   // only orders our work after the caller's (image producers).
-  hipStream_t own_stream = nullptr, stream = nullptr, match_stream = nullptr, user_stream = nullptr;
+  // A third stream takes the short, latency-bound post-processing (chain +
+  // emission) of frame t, so that the flow search of frame t+1 follows that of
+  // frame t back to back; the match tables are double-buffered for that.
+  hipStream_t own_stream = nullptr, stream = nullptr, match_stream = nullptr, post_stream = nullptr, user_stream = nullptr;
+  hipEvent_t ev_tables[2] = {nullptr, nullptr};  // match tables of buffer b complete
+  hipEvent_t ev_post[2] = {nullptr, nullptr};    // post-processing finished reading buffer b
+  bool ev_post_valid[2] = {false, false};
+  int64_t match_seq = 0;
+  int32_t *d_mchunk = nullptr;
   hipEvent_t ev_det[3] = {nullptr, nullptr, nullptr};   // slot fully detected + indexed
   hipEvent_t ev_read[3] = {nullptr, nullptr, nullptr};  // last match that read the slot
   bool ev_read_valid[3] = {false, false, false};
   hipEvent_t ev_user = nullptr;
   int32_t pair_prev = 1;
+  bool serial = false, own_post = false;
 
   bool allocated = false;
   int32_t dims[3] = {0, 0, 0};
@@ -65,8 +75,8 @@ struct Group {
   uint8_t *d_half = nullptr;                 // half-resolution images [S*2]
   uint64_t *d_rec = nullptr;
   int32_t *d_chunk_count = nullptr;
-  int32_t *d_best = nullptr;
-  int4 *d_chain = nullptr;
+  int32_t *d_best = nullptr, *d_best2[2] = {nullptr, nullptr};
+  int4 *d_chain = nullptr, *d_chain2[2] = {nullptr, nullptr};
   uint32_t *d_mask = nullptr;
   uint32_t epoch = 0;
   void *d_matches = nullptr;
@@ -84,13 +94,16 @@ struct Group {
     release();
     for (int k = 0; k < 3; k++) { if (ev_det[k]) (void)hipEventDestroy(ev_det[k]); if (ev_read[k]) (void)hipEventDestroy(ev_read[k]); }
     if (ev_user) (void)hipEventDestroy(ev_user);
-    if (match_stream) (void)hipStreamDestroy(match_stream);
+    for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); }
+    if (post_stream && own_post) (void)hipStreamDestroy(post_stream);
+    if (match_stream && !serial) (void)hipStreamDestroy(match_stream);
     if (own_stream) (void)hipStreamDestroy(own_stream);
   }
   int32_t pairs() const { return pair_cur | (pair_prev << 8); }
   int32_t sync_all() {
     VH_HIP(hipStreamSynchronize(stream));
     VH_HIP(hipStreamSynchronize(match_stream));
+    VH_HIP(hipStreamSynchronize(post_stream));
     return VH_OK;
   }
 
@@ -99,6 +112,7 @@ struct Group {
     allocs.clear();
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
+    d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr;
     allocated = false;
   }
@@ -195,8 +209,12 @@ struct Group {
     if ((rc = dmalloc(&sets.tile_cnt, ns, true))) return rc;
     if ((rc = dmalloc(&d_rec, 2 * (size_t)S * std::max(g.nblocks, 1), false))) return rc;
     if ((rc = dmalloc(&d_chunk_count, 2 * (size_t)S * g.nchunks, true))) return rc;
-    if ((rc = dmalloc(&d_best, 4 * (size_t)S * cap, false))) return rc;
-    if ((rc = dmalloc(&d_chain, (size_t)S * cap, false))) return rc;
+    for (int k = 0; k < 2; k++) {
+      if ((rc = dmalloc(&d_best2[k], 4 * (size_t)S * cap, false))) return rc;
+      if ((rc = dmalloc(&d_chain2[k], (size_t)S * cap, false))) return rc;
+    }
+    d_best = d_best2[0]; d_chain = d_chain2[0];
+    if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 1023) / 1024), true))) return rc;
     if ((rc = dmalloc((uint8_t **)&d_matches, (size_t)S * mcap * sizeof(vh_p_match), false))) return rc;
     if ((rc = dmalloc(&d_match_count, (size_t)S, true))) return rc;
     if (p.half_resolution)
@@ -204,6 +222,7 @@ struct Group {
     allocated = true;
     pair_cur = 0; pair_prev = 1; frames = 0; epoch = 0; last_method = -1; bucketed = false;
     for (int k = 0; k < 3; k++) ev_read_valid[k] = false;
+    ev_post_valid[0] = ev_post_valid[1] = false; match_seq = 0;
     // every slot starts "detected" (empty): matches may wait on any of them
     for (int k = 0; k < 3; k++) VH_HIP(hipEventRecord(ev_det[k], stream));
     return VH_OK;
@@ -233,23 +252,17 @@ struct Group {
   }
 
   // ---- detect + bin ------------------------------------------------------
-  int32_t zero_bin_counters(int32_t set0, int32_t nsets) {
-    const size_t nrow = 4 * (size_t)dims[1];
-    VH_HIP(hipMemsetAsync(sets.hist + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
-    VH_HIP(hipMemsetAsync(sets.cursor + (size_t)set0 * sets.nbins, 0, sizeof(int32_t) * (size_t)nsets * sets.nbins, stream));
-    VH_HIP(hipMemsetAsync(sets.row_hist + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
-    VH_HIP(hipMemsetAsync(sets.row_cursor + (size_t)set0 * nrow, 0, sizeof(int32_t) * (size_t)nsets * nrow, stream));
+  int32_t zero_bin_counters(int32_t set0, int32_t nsets, int32_t *extra = nullptr, int64_t n_extra = 0) {
+    // one launch instead of a memset per array
+    vh_launch_zero_counters(sets, set0, nsets, extra, n_extra, stream);
+    VH_HIP(hipGetLastError());
     return VH_OK;
   }
 
   // staged: the histograms and per-bin member lists were already produced by
   // emit_features; otherwise (caller-supplied features) build them here.
   int32_t bin_sets(int32_t set0, int32_t nsets, bool staged) {
-    if (!staged) {
-      int32_t rc = zero_bin_counters(set0, nsets);
-      if (rc) return rc;
-      { Scope sc(this, "bin_hist", stream); vh_launch_bin_hist(sets, set0, nsets, stream); }
-    }
+    if (!staged) { Scope sc(this, "bin_hist", stream); vh_launch_bin_hist(sets, set0, nsets, stream); }
     { Scope sc(this, "bin_scan", stream); vh_launch_bin_scan(sets, set0, nsets, stream); }
     if (!staged) { Scope sc(this, "bin_fill", stream); vh_launch_bin_fill(sets, set0, nsets, stream); }
     { Scope sc(this, "bin_sort", stream); vh_launch_bin_sort(sets, set0, nsets, staged ? 1 : 0, stream); }
@@ -276,9 +289,7 @@ struct Group {
       VH_HIP(hipStreamWaitEvent(stream, ev_user, 0));
     }
     if (ev_read_valid[pair_cur]) VH_HIP(hipStreamWaitEvent(stream, ev_read[pair_cur], 0));
-    VH_HIP(hipMemsetAsync(sets.count + set0, 0, sizeof(int32_t) * nsets, stream));
-    VH_HIP(hipMemsetAsync(d_chunk_count, 0, sizeof(int32_t) * 2 * (size_t)S * g.nchunks, stream));
-    if ((rc = zero_bin_counters(set0, nsets))) return rc;
+    if ((rc = zero_bin_counters(set0, nsets, d_chunk_count, 2 * (int64_t)S * g.nchunks))) return rc;
     VhImages im{};
     im.base[0] = (const uint8_t *)dI1; im.base[1] = (const uint8_t *)dI2;
     im.stride = stride; im.ncam = dI2 ? 2 : 1; im.S = S; im.pair_cur = pair_cur;
@@ -339,30 +350,38 @@ struct Group {
     if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
     if (!allocated) return VH_ERR_STATE;
     const VhMatchArgs a = match_args(method);
-    hipStream_t ms = match_stream;
+    hipStream_t ms = match_stream, ps = post_stream;
+    const int32_t buf = (int32_t)(match_seq++ & 1);
     // the current slot's detection+indexing must be complete (the previous
-    // slot's finished earlier on the same stream)
+    // slot's finished earlier on the same stream), and the post-processing that
+    // last read this table buffer (two matches ago) must be done with it
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_cur], 0));
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_prev], 0));
+    if (ev_post_valid[buf]) VH_HIP(hipStreamWaitEvent(ms, ev_post[buf], 0));
+    { Scope sc(this, "match_stereo", ms); vh_launch_match_stereo(sets, a, d_best2[buf], ms); }
+    { Scope sc(this, "match_flow", ms); vh_launch_match_flow(sets, a, d_best2[buf], ms); }
+    VH_HIP(hipGetLastError());
+    VH_HIP(hipEventRecord(ev_tables[buf], ms));
+    VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
+    VH_HIP(hipMemsetAsync(d_mchunk, 0, sizeof(int32_t) * (size_t)S * ((cap + 1023) / 1024), ps));
     if (method == VH_METHOD_FLOW) {
       if (!d_mask) {
         int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) return rc;
-        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ms));
+        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ps));
         epoch = 0;
       }
       if (++epoch >= 4095) {
-        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ms));
+        VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ps));
         epoch = 1;
       }
     }
-    { Scope sc(this, "match_stereo", ms); vh_launch_match_stereo(sets, a, d_best, ms); }
-    { Scope sc(this, "match_flow", ms); vh_launch_match_flow(sets, a, d_best, ms); }
-    { Scope sc(this, "chain", ms); vh_launch_chain(sets, a, method, d_best, d_chain, d_mask, epoch, ms); }
-    { Scope sc(this, "emit_matches", ms); vh_launch_emit_matches(sets, a, method, d_chain, d_mask, epoch, d_matches, mcap, d_match_count, ms); }
+    { Scope sc(this, "chain", ps); vh_launch_chain(sets, a, method, d_best2[buf], d_chain2[buf], d_mask, epoch, d_mchunk, ps); }
+    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_mchunk, ps); }
     VH_HIP(hipGetLastError());
-    // both slots stay in use until this point of the match stream
-    VH_HIP(hipEventRecord(ev_read[pair_cur], ms)); ev_read_valid[pair_cur] = true;
-    VH_HIP(hipEventRecord(ev_read[pair_prev], ms)); ev_read_valid[pair_prev] = true;
+    VH_HIP(hipEventRecord(ev_post[buf], ps)); ev_post_valid[buf] = true;
+    // both slots stay in use until this point of the post stream
+    VH_HIP(hipEventRecord(ev_read[pair_cur], ps)); ev_read_valid[pair_cur] = true;
+    VH_HIP(hipEventRecord(ev_read[pair_prev], ps)); ev_read_valid[pair_prev] = true;
     last_method = method; bucketed = false;
     return VH_OK;
   }
@@ -378,14 +397,14 @@ struct Group {
       return *n > capo ? VH_ERR_CAPACITY : VH_OK;
     }
     int32_t cnt = 0;
-    VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, match_stream));
-    VH_HIP(hipStreamSynchronize(match_stream));
+    VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipStreamSynchronize(post_stream));
     *n = cnt;
     const int32_t k = std::min(std::min(cnt, mcap), capo);
     if (k > 0) {
       VH_HIP(hipMemcpyAsync(out, (const uint8_t *)d_matches + (size_t)s * mcap * sizeof(vh_p_match),
-                            sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, match_stream));
-      VH_HIP(hipStreamSynchronize(match_stream));
+                            sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, post_stream));
+      VH_HIP(hipStreamSynchronize(post_stream));
     }
     return (cnt > capo || cnt > mcap) ? VH_ERR_CAPACITY : VH_OK;
   }
@@ -418,8 +437,8 @@ struct Group {
         for (int32_t r = 0; r < 4; r++) nf[4 * s + r] = all[vh_role_set(S, pairs(), s, r)];
     }
     if (nm) {
-      VH_HIP(hipMemcpyAsync(nm, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, match_stream));
-      VH_HIP(hipStreamSynchronize(match_stream));
+      VH_HIP(hipMemcpyAsync(nm, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+      VH_HIP(hipStreamSynchronize(post_stream));
     }
     return VH_OK;
   }
@@ -435,6 +454,7 @@ struct Group {
     const int32_t set = vh_role_set(S, pairs(), 0, role);
     const int32_t slot = (role >= 2) ? pair_cur : pair_prev;
     if (ev_read_valid[slot]) VH_HIP(hipStreamWaitEvent(stream, ev_read[slot], 0));
+    { int32_t rz = zero_bin_counters(set, 1); if (rz) return rz; }  // also clears the count, set right below
     if (n) VH_HIP(hipMemcpyAsync(sets.feat + (size_t)set * cap * 12, m, sizeof(int32_t) * 12 * (size_t)n, hipMemcpyHostToDevice, stream));
     VH_HIP(hipMemcpyAsync(sets.count + set, &n, sizeof(int32_t), hipMemcpyHostToDevice, stream));
     VH_HIP(hipStreamSynchronize(stream));
@@ -506,13 +526,35 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
   if ((rc = select_device(device))) return rc;
   Group *gq = new Group();
   gq->p = *p; gq->device = device; gq->S = S; gq->req_features = mf; gq->req_matches = mm;
-  if (hipStreamCreateWithFlags(&gq->own_stream, hipStreamNonBlocking) != hipSuccess) {
+  // Both streams at the default priority: raising the detect stream's priority
+  // (so that detection finishes inside the shadow of the flow search) was
+  // measured and lost ~3 % -- the single-workgroup-per-set kernels then wait for
+  // the starved low-priority stream instead (profiles/, round 1).
+  int prio_lo = 0, prio_hi = 0;
+  if (getenv("VH_DET_PRIORITY")) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&gq->own_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
     t_last_error = "hipStreamCreateWithFlags failed";
     gq->own_stream = nullptr; delete gq;
     return VH_ERR_HIP;
   }
   gq->stream = gq->own_stream;
-  bool ok = hipStreamCreateWithFlags(&gq->match_stream, hipStreamNonBlocking) == hipSuccess;
+  // VH_SERIAL=1 (profiling aid): run matching on the detect stream, i.e. no
+  // overlap, so that per-kernel timings are exclusive
+  const char *serial = getenv("VH_SERIAL");
+  bool ok = true;
+  if (serial && serial[0] == '1') gq->match_stream = gq->post_stream = gq->own_stream, gq->serial = true;
+  else {
+    ok = hipStreamCreateWithPriority(&gq->match_stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
+    // The chain/emission step can run on a stream of its own (VH_POST_STREAM=1) so
+    // that consecutive flow searches run back to back; measured on MI355X this
+    // LOSES ~17 %: the short kernels starve beside the saturating flow search
+    // and delay the detection that waits for them.  Default: same stream.
+    if (ok && getenv("VH_POST_STREAM")) ok = hipStreamCreateWithPriority(&gq->post_stream, hipStreamNonBlocking, prio_lo) == hipSuccess, gq->own_post = true;
+    else gq->post_stream = gq->match_stream;
+  }
+  for (int k = 0; k < 2 && ok; k++)
+    ok = hipEventCreateWithFlags(&gq->ev_tables[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&gq->ev_post[k], hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < 3 && ok; k++)
     ok = hipEventCreateWithFlags(&gq->ev_det[k], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&gq->ev_read[k], hipEventDisableTiming) == hipSuccess;

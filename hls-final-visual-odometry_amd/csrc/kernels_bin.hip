@@ -27,6 +27,29 @@ __device__ __forceinline__ int32_t feature_bin(const int32_t *__restrict__ f, co
   return (c * s.ubn + bin_coord(u, s.binsize, s.ubn)) * s.vbn + bin_coord(v, s.binsize, s.vbn);
 }
 
+// Zero every per-frame counter of sets [set0, set0+nsets) -- feature counts,
+// bin and row histograms and cursors -- plus an optional extra array, in one launch.
+__global__ void zero_counters_kernel(VhSets s, int32_t set0, int32_t nsets, int32_t *__restrict__ extra, int64_t n_extra) {
+  const int64_t nb = (int64_t)nsets * s.nbins, nr = (int64_t)nsets * 4 * s.H;
+  const int64_t total = 2 * nb + 2 * nr + nsets + n_extra;
+  int32_t *hist = s.hist + (int64_t)set0 * s.nbins, *cur = s.cursor + (int64_t)set0 * s.nbins;
+  int32_t *rh = s.row_hist + (int64_t)set0 * 4 * s.H, *rc = s.row_cursor + (int64_t)set0 * 4 * s.H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t k = i;
+    if (k < nb) { hist[k] = 0; continue; }
+    k -= nb;
+    if (k < nb) { cur[k] = 0; continue; }
+    k -= nb;
+    if (k < nr) { rh[k] = 0; continue; }
+    k -= nr;
+    if (k < nr) { rc[k] = 0; continue; }
+    k -= nr;
+    if (k < nsets) { s.count[set0 + k] = 0; continue; }
+    k -= nsets;
+    extra[k] = 0;
+  }
+}
+
 __global__ void bin_hist_kernel(VhSets s, int32_t set0) {
   const int32_t set = set0 + blockIdx.y;
   const int32_t n = min(s.count[set], s.cap);
@@ -222,6 +245,13 @@ __global__ void ref_index_kernel(VhSets s, int32_t set, int32_t *__restrict__ bs
 // workgroups per set: the feature count lives on the device and a cap-sized
 // grid would be ~75 % empty workgroups at typical densities.
 static int32_t feature_blocks(const VhSets &s) { return std::min(std::max(s.cap / 1024, 8), 256); }
+
+void vh_launch_zero_counters(const VhSets &s, int32_t set0, int32_t nsets, int32_t *extra, int64_t n_extra,
+                             hipStream_t st) {
+  const int64_t total = 2 * (int64_t)nsets * s.nbins + 8 * (int64_t)nsets * s.H + nsets + n_extra;
+  const int32_t blocks = (int32_t)std::min<int64_t>((total + 1023) / 1024, 2048);
+  hipLaunchKernelGGL(zero_counters_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, s, set0, nsets, extra, n_extra);
+}
 
 void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
   dim3 grid(feature_blocks(s), nsets);

@@ -202,6 +202,9 @@ template <int N> struct DetTile {
   static constexpr int ROWS = (FH + NSEG - 1) / NSEG;
 };
 
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 as_s2(uint32_t x) { return __builtin_bit_cast(s2, x); }
+
 template <int N, bool IS_MIN> __device__ __forceinline__ int32_t fold_window(const int32_t (&w)[2 * N + 1]) {
   int32_t r = w[0];
 #pragma unroll
@@ -291,22 +294,33 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
 #pragma unroll
   for (int32_t plane = 0; plane < 2; plane++) {
     const int16_t *F = plane ? sF2 : sF1;
-    // (a) vertical window extrema, one column per lane, sliding down the rows
-    for (int32_t task = tid; task < T::FW * NSEGV; task += 256) {
-      const int32_t seg = task / T::FW, cx = task - seg * T::FW;
-      const int32_t a = N + seg * ROWSV;  // first output row of this segment
-      int32_t w[WN];
+    // (a) vertical window extrema, one column PAIR per lane (packed i16: v_pk_min_i16 /
+    //     v_pk_max_i16 do two columns per instruction), sliding down the rows
+    {
+      constexpr int CP = T::FP / 2;  // column pairs per row
+      constexpr int NSV = (256 / CP) > 0 ? (256 / CP) : 1;
+      constexpr int RSV = (VH_ROWS + NSV - 1) / NSV;
+      const uint32_t *F2 = (const uint32_t *)F;
+      uint32_t *vmin2 = (uint32_t *)sVmin, *vmax2 = (uint32_t *)sVmax;
+      for (int32_t task = tid; task < CP * NSV; task += 256) {
+        const int32_t seg = task / CP, cp = task - seg * CP;
+        const int32_t a = N + seg * RSV;  // first output row of this segment
+        s2 w[WN];
 #pragma unroll
-      for (int32_t k = 0; k < WN - 1; k++) w[k + 1] = F[min(a - N + k, ylim) * T::FP + cx];
+        for (int32_t k = 0; k < WN - 1; k++) w[k + 1] = as_s2(F2[min(a - N + k, ylim) * CP + cp]);
 #pragma unroll
-      for (int32_t i = 0; i < ROWSV; i++) {
-        const int32_t r = a + i;
-        if (r < T::FH - N) {
+        for (int32_t i = 0; i < RSV; i++) {
+          const int32_t r = a + i;
+          if (r < T::FH - N) {
 #pragma unroll
-          for (int32_t k = 0; k < WN - 1; k++) w[k] = w[k + 1];
-          w[WN - 1] = F[min(r + N, ylim) * T::FP + cx];
-          sVmin[(r - N) * T::FP + cx] = (int16_t)fold_window<N, true>(w);
-          sVmax[(r - N) * T::FP + cx] = (int16_t)fold_window<N, false>(w);
+            for (int32_t k = 0; k < WN - 1; k++) w[k] = w[k + 1];
+            w[WN - 1] = as_s2(F2[min(r + N, ylim) * CP + cp]);
+            s2 mn = w[0], mx = w[0];
+#pragma unroll
+            for (int32_t k = 1; k < WN; k++) { mn = __builtin_elementwise_min(mn, w[k]); mx = __builtin_elementwise_max(mx, w[k]); }
+            vmin2[(r - N) * CP + cp] = __builtin_bit_cast(uint32_t, mn);
+            vmax2[(r - N) * CP + cp] = __builtin_bit_cast(uint32_t, mx);
+          }
         }
       }
     }

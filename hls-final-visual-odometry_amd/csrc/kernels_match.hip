@@ -268,6 +268,14 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   }
 }
 
+// Survivors per emission chunk: one atomic per wave (the 64 lanes of a wave hold
+// consecutive features of one 1024-feature chunk), not one per lane -- 64
+// same-address atomics per wave made the chain kernel 8x slower.
+__device__ __forceinline__ void count_chunk(bool keep, int32_t *counter) {
+  const uint64_t bal = __ballot(keep);
+  if (bal && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(bal)) atomicAdd(counter, (int32_t)__popcll(bal));
+}
+
 // ---------------------------------------------------------------------- chain
 // Follows the circle of each driving feature through the per-pass tables and
 // records the index tuple (i1p,i2p,i1c,i2c), or z=-2 when the circle does not
@@ -281,7 +289,8 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
 // for its pixel with atomicMax(epoch<<20 | (0xFFFFF - i1c)); the lowest i1c of
 // this epoch wins, and no clearing between frames is needed.
 __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int32_t *__restrict__ best,
-                             int4 *__restrict__ chain, uint32_t *__restrict__ mask, uint32_t epoch) {
+                             int4 *__restrict__ chain, uint32_t *__restrict__ mask, uint32_t epoch,
+                             int32_t *__restrict__ mchunk, int32_t nchm) {
   const int32_t stream = blockIdx.y;
   const int32_t set1p = vh_role_set(a.S, a.pair_cur, stream, 0), set2p = vh_role_set(a.S, a.pair_cur, stream, 1);
   const int32_t set1c = vh_role_set(a.S, a.pair_cur, stream, 2), set2c = vh_role_set(a.S, a.pair_cur, stream, 3);
@@ -314,6 +323,7 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
       if (i1c2 == i && u1c >= u2c) r = make_int4(-1, -1, i, i2c);
     }
     out[i] = r;
+    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 10));
   } else {
     int4 r = make_int4(-1, -1, -2, -1);
     if (n2p > 0 && n1c > 0 && n2c > 0) {
@@ -326,75 +336,97 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
       if (i1p2 == i && u1p >= u2p && u1c >= u2c) r = make_int4(i, i2p, i1c, i2c);
     }
     out[i] = r;
+    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 10));
   }
   }  // grid-stride loop
 }
 
+// ------------------------------------------------------------------ flow_keep
+// Flow only: after every closing feature has bid for its pixel, keep the winner
+// (the reference's first writer, matcher.cpp:331-334), drop the others, and
+// count the survivors per emission chunk.
+__global__ void flow_keep_kernel(VhSets s, VhMatchArgs a, int4 *__restrict__ chain,
+                                 const uint32_t *__restrict__ mask, uint32_t epoch,
+                                 int32_t *__restrict__ mchunk, int32_t nchm) {
+  const int32_t stream = blockIdx.y;
+  const int32_t set1c = vh_role_set(a.S, a.pair_cur, stream, 2);
+  const int32_t n1c = min(s.count[set1c], s.cap);
+  int4 *__restrict__ ch = chain + (int64_t)stream * s.cap;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n1c; i += gridDim.x * blockDim.x) {
+    const int4 r = ch[i];
+    const int32_t *f = s.feat + ((int64_t)set1c * s.cap + i) * 12;
+    const bool win = r.z >= 0 && mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]] == ((epoch << 20) | (0xFFFFFu - (uint32_t)i));
+    if (r.z >= 0 && !win) ch[i].z = -2;
+    count_chunk(win, mchunk + stream * nchm + (i >> 10));
+  }
+}
+
 // --------------------------------------------------------------- emit_matches
-// One workgroup per stream: ordered compaction of the closed circles into
-// p_match records (48 B, src/matcher.h:89-104), in ascending order of the
-// driving feature index as the reference's loops emit them.
+// One workgroup per 1024 driving features: ordered compaction of the closed
+// circles into p_match records (48 B, src/matcher.h:89-104), in ascending order
+// of the driving feature index as the reference's loops emit them.  The offset of
+// a chunk is the sum of the survivor counts of the chunks before it.
 __global__ void __launch_bounds__(1024)
 emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restrict__ chain,
-                    const uint32_t *__restrict__ mask, uint32_t epoch, float *__restrict__ matches,
-                    int32_t mcap, int32_t *__restrict__ match_count) {
+                    float *__restrict__ matches, int32_t mcap, int32_t *__restrict__ match_count,
+                    const int32_t *__restrict__ mchunk, int32_t nchm) {
   __shared__ int32_t sWave[16];
-  __shared__ int32_t sTotal;
-  const int32_t stream = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ int32_t sBase;
+  const int32_t chunk = blockIdx.x, stream = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int32_t sets[4];
 #pragma unroll
   for (int32_t r = 0; r < 4; r++) sets[r] = vh_role_set(a.S, a.pair_cur, stream, r);
   const int32_t drive = (method == 2) ? sets[0] : sets[2];
   const int32_t n = min(s.count[drive], s.cap);
+  if (chunk * 1024 >= n && chunk != nchm - 1) return;
   const int4 *__restrict__ ch = chain + (int64_t)stream * s.cap;
   float *__restrict__ out = matches + (int64_t)stream * mcap * 12;
-  if (tid == 0) sTotal = 0;
+  // matches emitted by earlier chunks
+  int32_t part = 0;
+  for (int32_t k = tid; k < chunk; k += 1024) part += mchunk[stream * nchm + k];
+#pragma unroll
+  for (int32_t d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) sWave[w] = part;
   __syncthreads();
-  for (int32_t i0 = 0; i0 < n; i0 += 1024) {
-    const int32_t i = i0 + tid;
-    int4 r = make_int4(-1, -1, -2, -1);
-    if (i < n) r = ch[i];
-    bool keep = r.z >= 0;
-    uint32_t rec[12];
+  if (tid == 0) { int32_t t = 0; for (int32_t k = 0; k < 16; k++) t += sWave[k]; sBase = t; }
+  __syncthreads();
+  const int32_t base = sBase;
+  __syncthreads();
+
+  const int32_t i = chunk * 1024 + tid;
+  int4 r = make_int4(-1, -1, -2, -1);
+  if (i < n) r = ch[i];
+  const bool keep = r.z >= 0;
+  uint32_t rec[12];
 #pragma unroll
-    for (int32_t k = 0; k < 12; k++) rec[k] = (k % 3 == 2) ? 0xFFFFFFFFu : __float_as_uint(-1.0f);
-    if (keep) {
-      const int32_t idx[4] = {r.x, r.y, r.z, r.w};
-      int32_t u1c = 0, v1c = 0;
+  for (int32_t k = 0; k < 12; k++) rec[k] = (k % 3 == 2) ? 0xFFFFFFFFu : __float_as_uint(-1.0f);
+  if (keep) {
+    const int32_t idx[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-      for (int32_t k = 0; k < 4; k++) {
-        if (idx[k] >= 0) {
-          const int32_t *f = s.feat + ((int64_t)sets[k] * s.cap + idx[k]) * 12;
-          rec[3 * k + 0] = __float_as_uint((float)f[0]);
-          rec[3 * k + 1] = __float_as_uint((float)f[1]);
-          if (k == 2) { u1c = f[0]; v1c = f[1]; }
-        }
-        rec[3 * k + 2] = (uint32_t)idx[k];
+    for (int32_t k = 0; k < 4; k++) {
+      if (idx[k] >= 0) {
+        const int32_t *f = s.feat + ((int64_t)sets[k] * s.cap + idx[k]) * 12;
+        rec[3 * k + 0] = __float_as_uint((float)f[0]);
+        rec[3 * k + 1] = __float_as_uint((float)f[1]);
       }
-      if (method == 0)  // first writer per pixel (matcher.cpp:331)
-        keep = mask[(int64_t)stream * s.W * s.H + (int64_t)v1c * s.W + u1c] == ((epoch << 20) | (0xFFFFFu - (uint32_t)r.z));
+      rec[3 * k + 2] = (uint32_t)idx[k];
     }
-    // workgroup exclusive scan of keep
-    const uint64_t bal = __ballot(keep);
-    const int32_t before = __popcll(bal & ((1ull << lane) - 1));
-    if (lane == 0) sWave[w] = __popcll(bal);
-    __syncthreads();
-    int32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int32_t k = 0; k < 16; k++) { const int32_t c = sWave[k]; if (k < w) woff += c; tot += c; }
-    const int32_t base = sTotal;
-    const int32_t pos = base + woff + before;
-    if (keep && pos < mcap) {
-      uint4 *o = (uint4 *)(out + (int64_t)pos * 12);
-      o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-      o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
-      o[2] = make_uint4(rec[8], rec[9], rec[10], rec[11]);
-    }
-    __syncthreads();
-    if (tid == 0) sTotal = base + tot;
-    __syncthreads();
   }
-  if (tid == 0) match_count[stream] = sTotal;
+  const uint64_t bal = __ballot(keep);
+  const int32_t before = __popcll(bal & ((1ull << lane) - 1));
+  if (lane == 0) sWave[w] = __popcll(bal);
+  __syncthreads();
+  int32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int32_t k = 0; k < 16; k++) { const int32_t c = sWave[k]; if (k < w) woff += c; tot += c; }
+  const int32_t pos = base + woff + before;
+  if (keep && pos < mcap) {
+    uint4 *o = (uint4 *)(out + (int64_t)pos * 12);
+    o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+    o[2] = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+  }
+  if (chunk == nchm - 1 && tid == 0) match_count[stream] = base + tot;
 }
 
 }  // namespace
@@ -421,13 +453,17 @@ void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, 
   hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, st, s, fl, best);
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
-                     int4 *chain, uint32_t *mask, uint32_t epoch, hipStream_t st) {
+                     int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st) {
+  const int32_t nchm = (s.cap + 1023) / 1024;
   dim3 grid(std::min(std::max(s.cap / 1024, 8), 256), a.S);
-  hipLaunchKernelGGL(chain_kernel, grid, dim3(256), 0, st, s, a, method, best, chain, mask, epoch);
+  hipLaunchKernelGGL(chain_kernel, grid, dim3(256), 0, st, s, a, method, best, chain, mask, epoch, mchunk, nchm);
+  if (method == 0)
+    hipLaunchKernelGGL(flow_keep_kernel, grid, dim3(256), 0, st, s, a, chain, (const uint32_t *)mask, epoch, mchunk, nchm);
 }
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
-                            const uint32_t *mask, uint32_t epoch, void *matches, int32_t mcap,
-                            int32_t *match_count, hipStream_t st) {
-  hipLaunchKernelGGL(emit_matches_kernel, dim3(a.S), dim3(1024), 0, st, s, a, method, chain, mask, epoch,
-                     (float *)matches, mcap, match_count);
+                            void *matches, int32_t mcap, int32_t *match_count, const int32_t *mchunk,
+                            hipStream_t st) {
+  const int32_t nchm = (s.cap + 1023) / 1024;
+  hipLaunchKernelGGL(emit_matches_kernel, dim3(nchm, a.S), dim3(1024), 0, st, s, a, method, chain,
+                     (float *)matches, mcap, match_count, mchunk, nchm);
 }

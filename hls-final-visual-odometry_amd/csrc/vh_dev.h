@@ -124,6 +124,8 @@ void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t
 void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
                       int16_t *f1, int16_t *f2, hipStream_t st);
 
+void vh_launch_zero_counters(const VhSets &s, int32_t set0, int32_t nsets, int32_t *extra, int64_t n_extra,
+                             hipStream_t st);
 void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
 void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
 void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
@@ -134,9 +136,9 @@ void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, i
 void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
 void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
-                     int4 *chain, uint32_t *mask, uint32_t epoch, hipStream_t st);
+                     int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st);
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
-                            const uint32_t *mask, uint32_t epoch, void *matches, int32_t mcap,
-                            int32_t *match_count, hipStream_t st);
+                            void *matches, int32_t mcap, int32_t *match_count, const int32_t *mchunk,
+                            hipStream_t st);
 
 #endif
