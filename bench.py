@@ -132,12 +132,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", "128")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", "256")),
                     help="independent camera streams per GPU, stepped together")
     ap.add_argument("--frames", type=int, default=8, help="distinct frames per stream kept in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--groups", type=int, default=1, help="experiment: split the streams over G groups on separate HIP streams")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
     args = ap.parse_args()
@@ -164,29 +163,16 @@ def main():
     stride = H * bpl
 
     stream = torch.cuda.current_stream()
-    G = args.groups
-    if G > 1:
-        assert S % G == 0
-        Sg = S // G
-        grps = [pkg.StreamGroup(Sg, pkg.Params.default(), device=local_rank, max_features=32768, max_matches=32768) for _ in range(G)]
-        grp = grps[0]
+    grp = pkg.StreamGroup(S, pkg.Params.default(), device=local_rank, max_features=32768, max_matches=32768)
+    grp.setStream(stream.cuda_stream)  # orders the group's work after this stream's (the frame upload)
 
-        def step(k):
-            t = k % T
-            for gi, gq in enumerate(grps):
-                gq.pushBackDevice(frames[t, 0, gi * Sg].data_ptr(), frames[t, 1, gi * Sg].data_ptr(), stride, dims, False)
-            for gq in grps:
-                gq.matchFeatures(pkg.METHOD_QUAD)
-    else:
-        grp = pkg.StreamGroup(S, pkg.Params.default(), device=local_rank, max_features=32768, max_matches=32768)
-        grp.setStream(stream.cuda_stream)
-
-        def step(k):
-            t = k % T
-            grp.pushBackDevice(frames[t, 0].data_ptr(), frames[t, 1].data_ptr(), stride, dims, False)
-            grp.matchFeatures(pkg.METHOD_QUAD)
+    def step(k):
+        t = k % T
+        grp.pushBackDevice(frames[t, 0].data_ptr(), frames[t, 1].data_ptr(), stride, dims, False)
+        grp.matchFeatures(pkg.METHOD_QUAD)
 
     def fence():
+        grp.synchronize()  # the group's internal detect/match streams
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -108,7 +108,7 @@ struct Group {
   }
 
   void release() {
-    for (void *q : allocs) hipFree(q);
+    for (void *q : allocs) (void)hipFree(q);
     allocs.clear();
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
@@ -214,7 +214,7 @@ struct Group {
       if ((rc = dmalloc(&d_chain2[k], (size_t)S * cap, false))) return rc;
     }
     d_best = d_best2[0]; d_chain = d_chain2[0];
-    if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 1023) / 1024), true))) return rc;
+    if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 255) / 256), true))) return rc;
     if ((rc = dmalloc((uint8_t **)&d_matches, (size_t)S * mcap * sizeof(vh_p_match), false))) return rc;
     if ((rc = dmalloc(&d_match_count, (size_t)S, true))) return rc;
     if (p.half_resolution)
@@ -242,10 +242,10 @@ struct Group {
     for (auto &kv : prof_entries) {
       for (auto &pr : kv.second.pending) {
         float ms = 0;
-        hipEventSynchronize(pr.second);
-        hipEventElapsedTime(&ms, pr.first, pr.second);
+        (void)hipEventSynchronize(pr.second);
+        (void)hipEventElapsedTime(&ms, pr.first, pr.second);
         kv.second.ms += ms; kv.second.launches++;
-        hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
       }
       kv.second.pending.clear();
     }
@@ -290,21 +290,34 @@ struct Group {
     }
     if (ev_read_valid[pair_cur]) VH_HIP(hipStreamWaitEvent(stream, ev_read[pair_cur], 0));
     if ((rc = zero_bin_counters(set0, nsets, d_chunk_count, 2 * (int64_t)S * g.nchunks))) return rc;
-    VhImages im{};
-    im.base[0] = (const uint8_t *)dI1; im.base[1] = (const uint8_t *)dI2;
-    im.stride = stride; im.ncam = dI2 ? 2 : 1; im.S = S; im.pair_cur = pair_cur;
-    if (p.half_resolution) {
-      { Scope sc(this, "half_res", stream); vh_launch_half_res(im, d_half, g, stream); }
-      // half images are stored by image id; present them as one "camera" with unit stride
-      VhImages hm = im;
-      const int64_t isz = (int64_t)g.bplm * g.Hm;
-      hm.base[0] = d_half; hm.base[1] = d_half + isz; hm.stride = isz * im.ncam;
-      im = hm;
+    // All streams in one launch per kernel.  Splitting the group into sub-batches
+    // (VH_SUBBATCH=n), hoping that each sub-batch's latency-bound tail would hide
+    // beside the previous frame's flow search, was measured on MI355X and loses
+    // 9 % (n=2) to 34 % (n=8): fewer, larger launches win.
+    const int32_t ncam = dI2 ? 2 : 1;
+    int32_t nsub = 1;
+    if (const char *ev = getenv("VH_SUBBATCH")) nsub = std::max(1, std::min(atoi(ev), S));
+    const int32_t ssub = (S + nsub - 1) / nsub;
+    for (int32_t s0 = 0; s0 < S; s0 += ssub) {
+      const int32_t sn = std::min(ssub, S - s0);
+      VhImages im{};
+      im.base[0] = (const uint8_t *)dI1 + (int64_t)s0 * stride;
+      im.base[1] = dI2 ? (const uint8_t *)dI2 + (int64_t)s0 * stride : nullptr;
+      im.stride = stride; im.ncam = ncam; im.S = sn; im.S_total = S; im.s0 = s0; im.pair_cur = pair_cur;
+      uint64_t *rec = d_rec + (size_t)s0 * ncam * std::max(g.nblocks, 1);
+      int32_t *chunks = d_chunk_count + (size_t)s0 * ncam * g.nchunks;
+      if (p.half_resolution) {
+        const int64_t isz = (int64_t)g.bplm * g.Hm;
+        uint8_t *half = d_half + (int64_t)s0 * ncam * isz;
+        { Scope sc(this, "half_res", stream); vh_launch_half_res(im, half, g, stream); }
+        // half images are stored by image id; present them as cameras with stride ncam*isz
+        im.base[0] = half; im.base[1] = half + isz; im.stride = isz * ncam;
+      }
+      { Scope sc(this, "detect_nms", stream); vh_launch_detect_nms(im, g, rec, chunks, stream); }
+      { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, rec, chunks, sets, stream); }
+      VH_HIP(hipGetLastError());
+      if ((rc = bin_sets(set0 + 2 * s0, 2 * sn, true))) return rc;
     }
-    { Scope sc(this, "detect_nms", stream); vh_launch_detect_nms(im, g, d_rec, d_chunk_count, stream); }
-    { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, d_rec, d_chunk_count, sets, stream); }
-    VH_HIP(hipGetLastError());
-    if ((rc = bin_sets(set0, nsets, true))) return rc;
     VH_HIP(hipEventRecord(ev_det[pair_cur], stream));
     return VH_OK;
   }
@@ -363,7 +376,7 @@ struct Group {
     VH_HIP(hipGetLastError());
     VH_HIP(hipEventRecord(ev_tables[buf], ms));
     VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
-    VH_HIP(hipMemsetAsync(d_mchunk, 0, sizeof(int32_t) * (size_t)S * ((cap + 1023) / 1024), ps));
+    VH_HIP(hipMemsetAsync(d_mchunk, 0, sizeof(int32_t) * (size_t)S * ((cap + 255) / 256), ps));
     if (method == VH_METHOD_FLOW) {
       if (!d_mask) {
         int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) return rc;
@@ -753,7 +766,7 @@ int32_t vh_filters(int32_t device, const uint8_t *I, int32_t bpl, int32_t H, uin
   if (e == hipSuccess && dv) e = hipMemcpy(dv, ddv, n, hipMemcpyDeviceToHost);
   if (e == hipSuccess && f1) e = hipMemcpy(f1, df1, 2 * n, hipMemcpyDeviceToHost);
   if (e == hipSuccess && f2) e = hipMemcpy(f2, df2, 2 * n, hipMemcpyDeviceToHost);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) { t_last_error = hipGetErrorString(e); return VH_ERR_HIP; }
   return VH_OK;
 }
@@ -783,7 +796,7 @@ int32_t vh_compute_features(const vh_params *p, int32_t device, const uint8_t *I
       hipError_t e = hipStreamSynchronize(t.gq->stream);
       if (e == hipSuccess && du) e = hipMemcpy(du, d, np, hipMemcpyDeviceToHost);
       if (e == hipSuccess && dv) e = hipMemcpy(dv, d + np, np, hipMemcpyDeviceToHost);
-      hipFree(d);
+      (void)hipFree(d);
       if (e != hipSuccess) { t_last_error = hipGetErrorString(e); return VH_ERR_HIP; }
     }
   }

@@ -14,6 +14,11 @@
 #include "vh_dev.h"
 #include <algorithm>
 
+// Threads of the one-workgroup-per-set scan.  256, not 1024: a 1024-thread
+// workgroup needs 16 free wave slots on ONE CU at once and starves beside the
+// saturating flow search of the other stream.
+#define VH_SCAN_T 256
+
 namespace {
 
 __device__ __forceinline__ int32_t bin_coord(int32_t x, int32_t binsize, int32_t nb) {
@@ -63,20 +68,20 @@ __global__ void bin_hist_kernel(VhSets s, int32_t set0) {
 // One workgroup per set: exclusive scan of the histogram into bin_start, and
 // the list of query tiles (<= 64 consecutive bin-ordered features of one
 // (class, u-bin) column) the match kernel works through.
-__global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) {
-  __shared__ int32_t sPart[1024];
+__global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t set0) {
+  __shared__ int32_t sPart[VH_SCAN_T];
   __shared__ int32_t sCarry;
   const int32_t set = set0 + blockIdx.x, tid = threadIdx.x;
   const int32_t *__restrict__ hist = s.hist + (int64_t)set * s.nbins;
   int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
   if (tid == 0) sCarry = 0;
   __syncthreads();
-  for (int32_t b0 = 0; b0 < s.nbins; b0 += 1024) {
+  for (int32_t b0 = 0; b0 < s.nbins; b0 += VH_SCAN_T) {
     const int32_t b = b0 + tid;
     const int32_t v = (b < s.nbins) ? hist[b] : 0;
     sPart[tid] = v;
     __syncthreads();
-    for (int32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+    for (int32_t d = 1; d < VH_SCAN_T; d <<= 1) {  // Hillis-Steele inclusive scan
       const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
       __syncthreads();
       sPart[tid] += t;
@@ -85,7 +90,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
     const int32_t incl = sPart[tid], carry = sCarry;
     if (b < s.nbins) bs[b] = carry + incl - v;
     __syncthreads();
-    if (tid == 1023) sCarry = carry + incl;
+    if (tid == VH_SCAN_T - 1) sCarry = carry + incl;
     __syncthreads();
   }
   if (tid == 0) bs[s.nbins] = sCarry;
@@ -100,14 +105,14 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
   int4 *__restrict__ tiles = s.tiles + (int64_t)set * s.max_tiles;
   if (tid == 0) sCarry = 0;
   __syncthreads();
-  for (int32_t c0 = 0; c0 < ngroup; c0 += 1024) {
+  for (int32_t c0 = 0; c0 < ngroup; c0 += VH_SCAN_T) {
     const int32_t grp = c0 + tid;
     int32_t q0 = 0, q1 = 0;
     if (grp < ngroup) { q0 = bs[grp * s.tile_span]; q1 = bs[(grp + 1) * s.tile_span]; }
     const int32_t nt = (q1 - q0 + 63) >> 6;
     sPart[tid] = nt;
     __syncthreads();
-    for (int32_t d = 1; d < 1024; d <<= 1) {
+    for (int32_t d = 1; d < VH_SCAN_T; d <<= 1) {
       const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
       __syncthreads();
       sPart[tid] += t;
@@ -119,7 +124,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
     for (int32_t k = 0; k < nt; k++, t0++)
       if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + 64 * k, min(q1, q0 + 64 * k + 64), cls, 0);
     __syncthreads();
-    if (tid == 1023) sCarry = carry + incl;
+    if (tid == VH_SCAN_T - 1) sCarry = carry + incl;
     __syncthreads();
   }
   if (tid == 0) s.tile_cnt[set] = min(sCarry, s.max_tiles);
@@ -131,12 +136,12 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
   int32_t *__restrict__ rs = s.row_start + (int64_t)set * (nrow + 1);
   if (tid == 0) sCarry = 0;
   __syncthreads();
-  for (int32_t b0 = 0; b0 < nrow; b0 += 1024) {
+  for (int32_t b0 = 0; b0 < nrow; b0 += VH_SCAN_T) {
     const int32_t b = b0 + tid;
     const int32_t v = (b < nrow) ? rh[b] : 0;
     sPart[tid] = v;
     __syncthreads();
-    for (int32_t d = 1; d < 1024; d <<= 1) {
+    for (int32_t d = 1; d < VH_SCAN_T; d <<= 1) {
       const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
       __syncthreads();
       sPart[tid] += t;
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(VhSets s, int32_t set0) 
     const int32_t incl = sPart[tid], carry = sCarry;
     if (b < nrow) rs[b] = carry + incl - v;
     __syncthreads();
-    if (tid == 1023) sCarry = carry + incl;
+    if (tid == VH_SCAN_T - 1) sCarry = carry + incl;
     __syncthreads();
   }
   if (tid == 0) rs[nrow] = sCarry;
@@ -258,7 +263,7 @@ void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_
   hipLaunchKernelGGL(bin_hist_kernel, grid, dim3(256), 0, st, s, set0);
 }
 void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
-  hipLaunchKernelGGL(bin_scan_kernel, dim3(nsets), dim3(1024), 0, st, s, set0);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(nsets), dim3(VH_SCAN_T), 0, st, s, set0);
 }
 void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
   dim3 grid(feature_blocks(s), nsets);

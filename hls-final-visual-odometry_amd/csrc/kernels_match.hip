@@ -269,7 +269,7 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
 }
 
 // Survivors per emission chunk: one atomic per wave (the 64 lanes of a wave hold
-// consecutive features of one 1024-feature chunk), not one per lane -- 64
+// consecutive features of one 256-feature chunk), not one per lane -- 64
 // same-address atomics per wave made the chain kernel 8x slower.
 __device__ __forceinline__ void count_chunk(bool keep, int32_t *counter) {
   const uint64_t bal = __ballot(keep);
@@ -323,7 +323,7 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
       if (i1c2 == i && u1c >= u2c) r = make_int4(-1, -1, i, i2c);
     }
     out[i] = r;
-    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 10));
+    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 8));
   } else {
     int4 r = make_int4(-1, -1, -2, -1);
     if (n2p > 0 && n1c > 0 && n2c > 0) {
@@ -336,7 +336,7 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
       if (i1p2 == i && u1p >= u2p && u1c >= u2c) r = make_int4(i, i2p, i1c, i2c);
     }
     out[i] = r;
-    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 10));
+    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 8));
   }
   }  // grid-stride loop
 }
@@ -357,20 +357,20 @@ __global__ void flow_keep_kernel(VhSets s, VhMatchArgs a, int4 *__restrict__ cha
     const int32_t *f = s.feat + ((int64_t)set1c * s.cap + i) * 12;
     const bool win = r.z >= 0 && mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]] == ((epoch << 20) | (0xFFFFFu - (uint32_t)i));
     if (r.z >= 0 && !win) ch[i].z = -2;
-    count_chunk(win, mchunk + stream * nchm + (i >> 10));
+    count_chunk(win, mchunk + stream * nchm + (i >> 8));
   }
 }
 
 // --------------------------------------------------------------- emit_matches
-// One workgroup per 1024 driving features: ordered compaction of the closed
+// One 256-thread workgroup per 256 driving features: ordered compaction of the closed
 // circles into p_match records (48 B, src/matcher.h:89-104), in ascending order
 // of the driving feature index as the reference's loops emit them.  The offset of
 // a chunk is the sum of the survivor counts of the chunks before it.
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restrict__ chain,
                     float *__restrict__ matches, int32_t mcap, int32_t *__restrict__ match_count,
                     const int32_t *__restrict__ mchunk, int32_t nchm) {
-  __shared__ int32_t sWave[16];
+  __shared__ int32_t sWave[4];
   __shared__ int32_t sBase;
   const int32_t chunk = blockIdx.x, stream = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int32_t sets[4];
@@ -378,22 +378,22 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
   for (int32_t r = 0; r < 4; r++) sets[r] = vh_role_set(a.S, a.pair_cur, stream, r);
   const int32_t drive = (method == 2) ? sets[0] : sets[2];
   const int32_t n = min(s.count[drive], s.cap);
-  if (chunk * 1024 >= n && chunk != nchm - 1) return;
+  if (chunk * 256 >= n && chunk != nchm - 1) return;
   const int4 *__restrict__ ch = chain + (int64_t)stream * s.cap;
   float *__restrict__ out = matches + (int64_t)stream * mcap * 12;
   // matches emitted by earlier chunks
   int32_t part = 0;
-  for (int32_t k = tid; k < chunk; k += 1024) part += mchunk[stream * nchm + k];
+  for (int32_t k = tid; k < chunk; k += 256) part += mchunk[stream * nchm + k];
 #pragma unroll
   for (int32_t d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
   if (lane == 0) sWave[w] = part;
   __syncthreads();
-  if (tid == 0) { int32_t t = 0; for (int32_t k = 0; k < 16; k++) t += sWave[k]; sBase = t; }
+  if (tid == 0) { int32_t t = 0; for (int32_t k = 0; k < 4; k++) t += sWave[k]; sBase = t; }
   __syncthreads();
   const int32_t base = sBase;
   __syncthreads();
 
-  const int32_t i = chunk * 1024 + tid;
+  const int32_t i = chunk * 256 + tid;
   int4 r = make_int4(-1, -1, -2, -1);
   if (i < n) r = ch[i];
   const bool keep = r.z >= 0;
@@ -418,7 +418,7 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
   __syncthreads();
   int32_t woff = 0, tot = 0;
 #pragma unroll
-  for (int32_t k = 0; k < 16; k++) { const int32_t c = sWave[k]; if (k < w) woff += c; tot += c; }
+  for (int32_t k = 0; k < 4; k++) { const int32_t c = sWave[k]; if (k < w) woff += c; tot += c; }
   const int32_t pos = base + woff + before;
   if (keep && pos < mcap) {
     uint4 *o = (uint4 *)(out + (int64_t)pos * 12);
@@ -454,7 +454,7 @@ void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, 
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st) {
-  const int32_t nchm = (s.cap + 1023) / 1024;
+  const int32_t nchm = (s.cap + 255) / 256;
   dim3 grid(std::min(std::max(s.cap / 1024, 8), 256), a.S);
   hipLaunchKernelGGL(chain_kernel, grid, dim3(256), 0, st, s, a, method, best, chain, mask, epoch, mchunk, nchm);
   if (method == 0)
@@ -463,7 +463,7 @@ void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, cons
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
                             void *matches, int32_t mcap, int32_t *match_count, const int32_t *mchunk,
                             hipStream_t st) {
-  const int32_t nchm = (s.cap + 1023) / 1024;
-  hipLaunchKernelGGL(emit_matches_kernel, dim3(nchm, a.S), dim3(1024), 0, st, s, a, method, chain,
+  const int32_t nchm = (s.cap + 255) / 256;
+  hipLaunchKernelGGL(emit_matches_kernel, dim3(nchm, a.S), dim3(256), 0, st, s, a, method, chain,
                      (float *)matches, mcap, match_count, mchunk, nchm);
 }

@@ -103,8 +103,9 @@ struct VhImages {
   const uint8_t *base[2];  // left / right image of stream 0
   int64_t stride;          // bytes between consecutive streams
   int32_t ncam;            // 1 (mono / flow) or 2 (stereo)
-  int32_t S;               // streams
+  int32_t S;               // streams covered by this launch (a sub-batch of the group)
   int32_t pair_cur;        // ring slot the new features are written to
+  int32_t S_total, s0;     // streams of the group / first stream of this launch (base[] already point at it)
 };
 // image id = stream*ncam + cam
 __host__ __device__ inline const uint8_t *vh_image_ptr(const VhImages &im, int32_t id) {
@@ -112,7 +113,7 @@ __host__ __device__ inline const uint8_t *vh_image_ptr(const VhImages &im, int32
   return im.base[cam] + (int64_t)s * im.stride;
 }
 __host__ __device__ inline int32_t vh_image_set(const VhImages &im, int32_t id) {
-  return vh_set_id(im.S, im.pair_cur, id / im.ncam, id % im.ncam);
+  return vh_set_id(im.S_total, im.pair_cur, im.s0 + id / im.ncam, id % im.ncam);
 }
 
 // ---- launchers (defined in the kernels_*.hip files) ------------------------
