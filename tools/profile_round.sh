@@ -7,6 +7,7 @@ set -e
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --no-cpu > $OUT/bench_stats.log 2>&1
 tail -1 $OUT/bench_stats.log | cut -c1-300

@@ -40,13 +40,17 @@ def short(name):
     return NAMES.get(k, k)
 
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(stats))}
 
 per = collections.defaultdict(dict)
 for kind in ("fetch", "write"):
-    f = glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(src, kind, "*", "*counter_collection.csv"))
     acc, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
