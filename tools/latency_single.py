@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Single-stream and host-image (PCIe-inclusive) rates of the Matcher surface --
+context numbers for DESIGN.md section 4.4; never the bench `value`."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry
+
+pkg = entry.load_package()
+W, H = 1241, 376
+bpl = pkg.synth.bytes_per_line(W)
+dims = [W, H, bpl]
+seq = pkg.synth.stereo_sequence(W, H, 8, 12)
+
+m = pkg.Matcher(pkg.Params.default())
+for l, r in seq[:3]:
+    m.pushBack(l, r, dims, False); m.matchFeatures(2); m.getMatches()
+t0 = time.perf_counter(); n = 0
+for rep in range(5):
+    for l, r in seq:
+        m.pushBack(l, r, dims, False); m.matchFeatures(2); pm = m.getMatches(); n += 1
+dt = time.perf_counter() - t0
+print(f"single stream, host images, getMatches every frame (the VisualOdometryStereo::process pattern): "
+      f"{1e3 * dt / n:.3f} ms per pair = {n / dt:.0f} pairs/s, {len(pm)} matches")
+m.close()
+
+for S in (64, 256):
+    g = pkg.StreamGroup(S, pkg.Params.default(), max_features=32768, max_matches=32768)
+    L = [np.ascontiguousarray(np.stack([seq[t][0]] * S)) for t in range(8)]
+    R = [np.ascontiguousarray(np.stack([seq[t][1]] * S)) for t in range(8)]
+    for t in range(3):
+        g.pushBack(L[t], R[t], dims, False); g.matchFeatures(2)
+    g.synchronize()
+    t0 = time.perf_counter(); k = 0
+    for rep in range(2):
+        for t in range(8):
+            g.pushBack(L[t], R[t], dims, False); g.matchFeatures(2); k += 1
+    g.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"group of {S} streams, HOST images (pageable, synchronous H2D inside pushBack): {S * k / dt:.0f} pairs/s")
+    g.close()
