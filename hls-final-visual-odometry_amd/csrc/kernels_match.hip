@@ -65,8 +65,9 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   const int32_t lane = threadIdx.x & 63;
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
-  const int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (tile >= s.tile_cnt[qset]) return;
+  const int32_t ntile = s.tile_cnt[qset];
+  for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); tile < ntile;
+       tile += gridDim.x * 4) {
   const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
   const int32_t q0 = __builtin_amdgcn_readfirstlane(t.x), q1 = __builtin_amdgcn_readfirstlane(t.y);
   const int32_t c = __builtin_amdgcn_readfirstlane(t.z);
@@ -180,6 +181,7 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const int32_t r = (best_pos >= 0) ? cidx[best_pos] : 0;
     best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q]] = r;
   }
+  }  // tile loop
 }
 
 // -------------------------------------------------------------- match (stereo)
@@ -453,7 +455,14 @@ void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best
 void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
   const VhMatchArgs fl = filter_passes(a, 1);
   if (!fl.npass) return;
-  dim3 grid((s.max_tiles + 3) / 4, fl.npass, a.S);
+  // One workgroup per 4 tiles of the capacity-sized tile list (the kernel loops,
+  // so any grid is correct).  At typical densities ~75 % of these workgroups
+  // find no tile and exit at once; a tight grid (VH_FLOW_WGS=38) makes the flow
+  // search itself 20 % shorter but starves the detect stream beside it: 61.6 k
+  // vs 62.2 k pairs/s, and 58.4 k at 40 -- measured, so the full grid stays.
+  static const int wgs = [] { const char *e = getenv("VH_FLOW_WGS"); return e ? atoi(e) : 0; }();
+  const int32_t gx = wgs > 0 ? wgs : (s.max_tiles + 3) / 4;
+  dim3 grid(gx, fl.npass, a.S);
   // Dynamic-LDS padding (unused by the kernel) caps the flow search at 5 workgroups
   // = 20 waves per CU.  Alone it runs as fast as at 8 waves/SIMD (it is VALU-issue
   // bound); beside the detect stream it leaves that stream enough wave slots to
