@@ -293,6 +293,42 @@ def test_stream_group_equals_independent_matchers(pkg, ob, oracle, gpu):
     g.close()
 
 
+def test_pipelined_steps_without_host_sync(pkg, ob, oracle, gpu):
+    """pushBack(t+1) is issued while matchFeatures(t) is still running (two
+    internal streams, three ring slots): queue many steps without ever
+    synchronising, mixing methods and a replace, and only then read back."""
+    S, W, H, T = 3, 320, 160, 7
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    po = ob.Params.default()
+    seqs = [pkg.synth.stereo_sequence(W, H, T, disparity=4 + s, blur=4, seed=60 + s) for s in range(S)]
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in pair] for pair in seqs[s]] for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    stack = lambda t, c: np.stack([seqs[s][t][c] for s in range(S)])
+    methods = [2, 2, 0, 2, 1, 2]
+    for t in range(T):
+        g.pushBack(stack(t, 0), stack(t, 1), dims, False)
+        if t:
+            g.matchFeatures(methods[t - 1])
+    # replace the newest pair by an older frame and match again, still without a sync
+    g.pushBack(stack(2, 0), stack(2, 1), dims, True)
+    g.matchFeatures(2)
+    for s in range(S):
+        want = oracle.matching(po, dims, 2, F[s][T - 2][0], F[s][T - 2][1], F[s][2][0], F[s][2][1])
+        assert g.getMatches(s).tobytes() == want.tobytes()
+        assert np.array_equal(g.getFeatures(s, pkg.SET_1P), F[s][T - 2][0])
+        assert np.array_equal(g.getFeatures(s, pkg.SET_2C), F[s][2][1])
+    # and every intermediate step, re-run with a read-back after each match, agrees with the oracle
+    g2 = pkg.StreamGroup(S, pkg.Params.default())
+    for t in range(T):
+        g2.pushBack(stack(t, 0), stack(t, 1), dims, False)
+        if t:
+            g2.matchFeatures(methods[t - 1])
+            for s in range(S):
+                want = oracle.matching(po, dims, methods[t - 1], F[s][t - 1][0], F[s][t - 1][1], F[s][t][0], F[s][t][1])
+                assert g2.getMatches(s).tobytes() == want.tobytes(), (t, s)
+    g.close(); g2.close()
+
+
 # ------------------------------------------------ full-size configs: exact where the oracle is fast, properties beyond
 def test_kitti_stereo_quad_full_size(pkg, ob, oracle, gpu):
     """configs[1]: KITTI 1241x376 stereo quad-match, default parameters."""
