@@ -149,11 +149,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or bool(os.environ.get("VH_BENCH_FORCE_DIST"))  # the env switch rehearses the RCCL plumbing on one GPU
+    if use_dist:
+        # RCCL only carries the barrier and the MAX-reduced timing: streams never exchange data
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = entry.load_package()
     S, T = args.streams, args.frames
@@ -174,8 +176,8 @@ def main():
     def fence():
         grp.synchronize()  # the group's internal detect/match streams
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     k = 0
@@ -191,7 +193,7 @@ def main():
     dt = time.perf_counter() - t0
     grp.profileEnable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
@@ -254,8 +256,8 @@ def main():
             out["parity_checked"] = bool(got0.tobytes() == want.tobytes())
         print(json.dumps(out), flush=True)
     grp.close()
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
