@@ -42,6 +42,7 @@ __global__ void half_res_kernel(VhImages src, uint8_t *__restrict__ dst, VhGeom 
 
 // --------------------------------------------------------------- detect_nms
 // LDS: sI[IH][IWp] u8 | sF1[FH][FWp] i16 | sF2[FH][FWp] i16 | work-list count, entries | codes
+// (position code of a survivor = row-in-block << 6 | column-in-block)
 //
 // Tile geometry (n = nms_n): the tile owns tbx x tby NMS blocks whose first
 // pixel is (n+7 + bx0*(n+1), n+7 + by0*(n+1)); responses are needed n pixels
@@ -167,7 +168,7 @@ detect_nms_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__
         if (outside && (is_min ? (cur < val) : (cur > val))) { ok = false; break; }
       }
     }
-    if (ok) sCode[owner * 4 + c] = (uint16_t)((cy - fy) * n1 + (cx - fx));
+    if (ok) sCode[owner * 4 + c] = (uint16_t)(((cy - fy) << 6) | (cx - fx));
   }
   __syncthreads();
   if (have_block) {
@@ -218,8 +219,6 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   using T = DetTile<N>;
   constexpr int N1 = T::N1, WN = 2 * N + 1;
   constexpr int VH_ROWS = T::FH - 2 * N;                       // rows that can hold a block extremum
-  constexpr int NSEGV = (256 / T::FW) > 0 ? (256 / T::FW) : 1;
-  constexpr int ROWSV = (VH_ROWS + NSEGV - 1) / NSEGV;
   constexpr int X_BYTES = (T::IH * T::IP > 4 * VH_ROWS * T::FP) ? T::IH * T::IP : 4 * VH_ROWS * T::FP;
   __shared__ __attribute__((aligned(16))) int16_t sF1[T::FH * T::FP];
   __shared__ __attribute__((aligned(16))) int16_t sF2[T::FH * T::FP];
@@ -335,11 +334,11 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
 #pragma unroll
         for (int32_t i = 0; i < N1; i++) {
           const int32_t cur = b[j * T::FP + i];
-          if (cur < vn) { vn = cur; pn = j * N1 + i; } else if (cur > vx) { vx = cur; px = j * N1 + i; }  // first extremum wins
+          if (cur < vn) { vn = cur; pn = (j << 6) | i; } else if (cur > vx) { vx = cur; px = (j << 6) | i; }  // first extremum wins
         }
       }
       if (vn <= -g.tau) {  // threshold (matcher.cpp:427,451)
-        const int32_t dy = pn / N1, dx = pn - dy * N1;
+        const int32_t dy = pn >> 6, dx = pn & 63;
         const int16_t *v = sVmin + (fy + dy - N) * T::FP;
         int32_t m = v[min(fx + dx - N, xlim)];
 #pragma unroll
@@ -347,7 +346,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
         if (m >= vn) cmin = (uint32_t)pn;
       }
       if (vx >= g.tau) {  // (matcher.cpp:439,463)
-        const int32_t dy = px / N1, dx = px - dy * N1;
+        const int32_t dy = px >> 6, dx = px & 63;
         const int16_t *v = sVmax + (fy + dy - N) * T::FP;
         int32_t m = v[min(fx + dx - N, xlim)];
 #pragma unroll
@@ -436,18 +435,21 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   for (int32_t w = 0; w < (tid >> 6); w++) woff += sWave[w];
   const int32_t total = sWave[0] + sWave[1] + sWave[2] + sWave[3];
   int32_t pos = woff + incl - mine;
+  {
+    // position code = (row in block) << 6 | (column in block); block coordinates
+    // advance incrementally (one division per lane, not one per block and code)
+    const int32_t blk0 = chunk * VH_CHUNK + tid * 4;
+    int32_t by = blk0 / g.nbx, bx = blk0 - by * g.nbx;
 #pragma unroll
-  for (int32_t k = 0; k < 4; k++) {
-    const int32_t blk = chunk * VH_CHUNK + tid * 4 + k;
-    const int32_t by = blk / g.nbx, bx = blk - by * g.nbx;
-    const int32_t px = g.n + VH_MARGIN + bx * n1, py = g.n + VH_MARGIN + by * n1;
+    for (int32_t k = 0; k < 4; k++) {
+      const int32_t px = g.n + VH_MARGIN + bx * n1, py = g.n + VH_MARGIN + by * n1;
 #pragma unroll
-    for (int32_t q = 0; q < 4; q++) {
-      const uint32_t pc = (uint32_t)(codes[k] >> (16 * q)) & 0xFFFF;
-      if (pc != VH_NO_CODE) {
-        const int32_t dj = pc / n1, di = pc - dj * n1;
-        sList[pos++] = (uint32_t)(px + di) | ((uint32_t)(py + dj) << 14) | ((uint32_t)q << 28);
+      for (int32_t q = 0; q < 4; q++) {
+        const uint32_t pc = (uint32_t)(codes[k] >> (16 * q)) & 0xFFFF;
+        if (pc != VH_NO_CODE)
+          sList[pos++] = (uint32_t)(px + (pc & 63)) | ((uint32_t)(py + (pc >> 6)) << 14) | ((uint32_t)q << 28);
       }
+      if (++bx == g.nbx) { bx = 0; by++; }
     }
   }
   __syncthreads();
