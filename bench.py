@@ -41,12 +41,17 @@ def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
     phase-shifted so that no two streams of a rank see identical frames."""
     bpl = pkg.synth.bytes_per_line(W)
     out = np.zeros((n_frames, 2, n_streams, H, bpl), np.uint8)
+    cache = {}  # (seed, k) -> (left, right): streams 8 apart share the sequence, shifted in time
+
+    def pair(seed, k):
+        if (seed, k) not in cache:
+            dx, dy = (5 * k) % 20, k % 20
+            cache[(seed, k)] = (pkg.synth.frame(W, H, dx, dy, 8, 1, seed), pkg.synth.frame(W, H, dx + 12, dy, 8, 1, seed))
+        return cache[(seed, k)]
+
     for s, (gs, seed, phase) in enumerate(stream_assignment(rank, n_streams)):
         for t in range(n_frames):
-            k = t + phase
-            dx, dy = (5 * k) % 20, k % 20
-            out[t, 0, s] = pkg.synth.frame(W, H, dx, dy, 8, 1, seed)
-            out[t, 1, s] = pkg.synth.frame(W, H, dx + 12, dy, 8, 1, seed)
+            out[t, 0, s], out[t, 1, s] = pair(seed, t + phase)
     return out, bpl
 
 
