@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "vh_abi_version", "vh_device_count", "vh_error_string", "vh_last_error", "vh_default_params",
     "vh_create", "vh_create_ex", "vh_destroy", "vh_set_intrinsics", "vh_push_back", "vh_push_back_device",
     "vh_match_features", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
-    "vh_set_stream", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match",
+    "vh_set_stream", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_push_back_device",
     "vh_group_push_back", "vh_group_match_features", "vh_group_get_matches", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
@@ -114,6 +114,7 @@ def _lib():
             "vh_filters": [i32, vp, i32, i32, vp, vp, vp, vp],
             "vh_create_index": [vp, i32, vp, vp, i32, vp, vp],
             "vh_match_all": [vp, i32, vp, vp, i32, vp, i32, i32, vp],
+            "vh_match_all_prior": [vp, i32, vp, vp, i32, vp, i32, i32, f64, f64, vp],
             "vh_match": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp],
             "vh_group_create": [vp, i32, i32, i32, i32, vp], "vh_group_destroy": [vp], "vh_group_streams": [vp],
             "vh_group_push_back_device": [vp, vp, vp, i64, vp, i32],
@@ -377,6 +378,16 @@ def match_all(param: Params, dims, m1, m2, flow: bool = True, device: int = 0):
     best = np.zeros(max(n1, 1), np.int32)
     _check(_lib().vh_match_all(C.byref(param), device, _dims(dims), _ptr(m1), n1, _ptr(m2), n2, 1 if flow else 0,
                                _ptr(best)), "vh_match_all")
+    return best[:n1]
+
+
+def match_all_prior(param: Params, dims, m1, m2, u_: float, v_: float, flow: bool = True, device: int = 0):
+    """Matcher::findMatch with the u_,v_ prediction term (reference src/matcher.cpp:257-262)."""
+    m1, n1 = _feat(m1)
+    m2, n2 = _feat(m2)
+    best = np.zeros(max(n1, 1), np.int32)
+    _check(_lib().vh_match_all_prior(C.byref(param), device, _dims(dims), _ptr(m1), n1, _ptr(m2), n2,
+                                     1 if flow else 0, float(u_), float(v_), _ptr(best)), "vh_match_all_prior")
     return best[:n1]
 
 

@@ -857,6 +857,26 @@ int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3], 
   return VH_OK;
 }
 
+int32_t vh_match_all_prior(const vh_params *p, int32_t device, const int32_t dims[3], const int32_t *m1, int32_t n1,
+                           const int32_t *m2, int32_t n2, int32_t flow, double u_, double v_, int32_t *best) {
+  if (!p || !dims || (n1 > 0 && !best)) return VH_ERR_INVALID_ARG;
+  Temp t;
+  int32_t rc;
+  if ((rc = group_new(p, device, 1, std::max(std::max(n1, n2), 64), 1, &t.gq))) return rc;
+  const int32_t d[3] = {dims[0], dims[1], std::max(dims[2], dims[0])};
+  Group *gq = t.gq;
+  if ((rc = gq->ensure(d))) return rc;
+  if ((rc = gq->load_features(VH_SET_1C, m1, n1))) return rc;
+  if ((rc = gq->load_features(VH_SET_1P, m2, n2))) return rc;
+  VhMatchArgs a = gq->match_args(VH_METHOD_FLOW);
+  a.npass = 1; a.pass[0] = {VH_SET_1C, VH_SET_1P, flow ? 1 : 0, 0};
+  vh_launch_match_prior(gq->sets, a, u_, v_, gq->d_best, gq->stream);
+  VH_HIP(hipGetLastError());
+  if (n1) VH_HIP(hipMemcpyAsync(best, gq->d_best, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, gq->stream));
+  VH_HIP(hipStreamSynchronize(gq->stream));
+  return VH_OK;
+}
+
 int32_t vh_match(const vh_params *p, int32_t device, const int32_t dims[3], int32_t method, const int32_t *m1p,
                  int32_t n1p, const int32_t *m2p, int32_t n2p, const int32_t *m1c, int32_t n1c,
                  const int32_t *m2c, int32_t n2c, vh_p_match *out, int32_t cap, int32_t *n) {

@@ -274,6 +274,51 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   }
 }
 
+// ------------------------------------------------------------ match (prior term)
+// findMatch with the u_,v_ distance term (matcher.cpp:257-262).  The cost is no
+// longer an integer, so the key trick does not apply: one lane per query walks
+// its own bin range in the reference's order (u_bin, v_bin, list position) and
+// keeps the first strict minimum, all in double exactly as the reference
+// (sqrt is the correctly rounded IEEE one; du*du+dv*dv is exact in double).
+__global__ void match_prior_kernel(VhSets s, VhMatchArgs a, double u_, double v_, int32_t *__restrict__ best) {
+  const int32_t qset = vh_role_set(a.S, a.pair_cur, 0, a.pass[0].qset);
+  const int32_t cset = vh_role_set(a.S, a.pair_cur, 0, a.pass[0].cset);
+  const int32_t nq = min(s.count[qset], s.cap);
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const int32_t *q = s.feat + ((int64_t)qset * s.cap + i) * 12;
+  const int32_t u1 = q[0], v1 = q[1], c = q[3];
+  const uint4 a0 = *(const uint4 *)(q + 4), a1 = *(const uint4 *)(q + 8);
+  const int32_t rv = a.pass[0].flow ? a.radius : a.disp_tol;
+  const int32_t u_lo = u1 - a.radius, u_hi = u1 + a.radius, v_lo = v1 - rv, v_hi = v1 + rv;
+  const int32_t ub0 = min(max(u_lo, 0) / s.binsize, s.ubn - 1), ub1 = min(max(u_hi, 0) / s.binsize, s.ubn - 1);
+  const int32_t vb0 = min(max(v_lo, 0) / s.binsize, s.vbn - 1), vb1 = min(max(v_hi, 0) / s.binsize, s.vbn - 1);
+  const int32_t *__restrict__ cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
+  const uint32_t *__restrict__ cuv = s.s_uv + (int64_t)cset * s.cap;
+  const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
+  double min_cost = 10000000;  // matcher.cpp:222
+  int32_t min_pos = -1;
+  for (int32_t ub = ub0; ub <= ub1; ub++) {
+    const int32_t row = (c * s.ubn + ub) * s.vbn;
+    for (int32_t p = cbs[row + vb0]; p < cbs[row + vb1 + 1]; p++) {
+      const uint32_t uv2 = cuv[p];
+      const int32_t u2 = uv2 & 0xFFFF, v2 = uv2 >> 16;
+      if (u2 < u_lo || u2 > u_hi || v2 < v_lo || v2 > v_hi) continue;
+      const uint4 b0 = cdesc[2 * (int64_t)p], b1 = cdesc[2 * (int64_t)p + 1];
+      uint32_t sad = sad4(a0.x, b0.x, 0);
+      sad = sad4(a0.y, b0.y, sad); sad = sad4(a0.z, b0.z, sad); sad = sad4(a0.w, b0.w, sad);
+      sad = sad4(a1.x, b1.x, sad); sad = sad4(a1.y, b1.y, sad); sad = sad4(a1.z, b1.z, sad); sad = sad4(a1.w, b1.w, sad);
+      double cost = (double)sad;
+      if (u_ >= 0 && v_ >= 0) {
+        const double du = (double)u2 - u_, dv = (double)v2 - v_;
+        cost += 4 * sqrt(du * du + dv * dv);
+      }
+      if (cost < min_cost) { min_cost = cost; min_pos = p; }
+    }
+  }
+  best[i] = min_pos >= 0 ? s.s_idx[(int64_t)cset * s.cap + min_pos] : 0;
+}
+
 // Survivors per emission chunk: one atomic per wave (the 64 lanes of a wave hold
 // consecutive features of one 256-feature chunk), not one per lane -- 64
 // same-address atomics per wave made the chain kernel 8x slower.
@@ -451,6 +496,10 @@ void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best
   if (!sr.npass) return;
   dim3 grid(std::min(std::max(s.cap / 1024, 8), 1024), sr.npass, a.S);  // 4 tiles of 64 queries per workgroup per trip
   hipLaunchKernelGGL(match_rows_kernel, grid, dim3(256), 0, st, s, sr, best);
+}
+void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, double v_, int32_t *best,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(match_prior_kernel, dim3((s.cap + 127) / 128), dim3(128), 0, st, s, a, u_, v_, best);
 }
 void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
   const VhMatchArgs fl = filter_passes(a, 1);

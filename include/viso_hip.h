@@ -162,6 +162,14 @@ int32_t vh_create_index(const vh_params *p, int32_t device, const int32_t dims[3
 int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3],
                      const int32_t *m1, int32_t n1, const int32_t *m2, int32_t n2,
                      int32_t flow, int32_t *best);
+/* Matcher::findMatch with its optional match-prediction term
+ * (src/matcher.cpp:257-262): cost = SAD + 4*||(u2,v2)-(u_,v_)|| evaluated and
+ * compared in double, as the reference does.  No caller in the reference passes
+ * u_,v_ (they default to -1 = off); provided so that the whole primitive is
+ * covered.  Not on the throughput path (one lane per query, double math). */
+int32_t vh_match_all_prior(const vh_params *p, int32_t device, const int32_t dims[3],
+                           const int32_t *m1, int32_t n1, const int32_t *m2, int32_t n2,
+                           int32_t flow, double u_, double v_, int32_t *best);
 /* Matcher::matching (src/matcher.h:218, src/matcher.cpp:274-344) on
  * caller-supplied feature arrays. Unused sets: NULL/0. */
 int32_t vh_match(const vh_params *p, int32_t device, const int32_t dims[3], int32_t method,

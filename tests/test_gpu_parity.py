@@ -52,6 +52,20 @@ def test_index_findmatch_matching_golden(name, pkg, ob, oracle, gpu):
     assert pm.tobytes() == z["p_match"].tobytes()
 
 
+def test_find_match_prior_term(pkg, ob, oracle, gpu):
+    """a9, optional branch: cost + 4*||(u2,v2)-(u_,v_)|| in double (src/matcher.cpp:257-262),
+    against the golden table produced by the reference itself and against the oracle."""
+    p, dims, Ip, Ic, z = load_golden("small_default", pkg, pkg.Params)
+    g = np.load(os.path.join(GOLDEN, "find_match_prior.npz"))
+    got = pkg.match_all_prior(p, dims, z["max2c"], z["max2p"], float(g["u_"]), float(g["v_"]))
+    assert np.array_equal(got, g["best"])
+    po = ob.Params.default(match_radius=90, match_binsize=37)
+    pg = pkg.Params.default(match_radius=90, match_binsize=37)
+    for u_, v_, flow in ((10.5, 300.25, True), (0.0, 0.0, False), (-1.0, 50.0, True)):
+        want = oracle.match_all_prior(po, dims, z["max2c"], z["max2p"], u_, v_, flow=flow)
+        assert np.array_equal(pkg.match_all_prior(pg, dims, z["max2c"], z["max2p"], u_, v_, flow=flow), want)
+
+
 @pytest.mark.parametrize("case", ["kitti_1241x376", "seq_1024x284"])
 def test_known_answers_full_size(case, pkg, oracle, gpu):
     """SURVEY Appendix-B sizes through the stateful Matcher surface (mono flow = configs[0])."""
