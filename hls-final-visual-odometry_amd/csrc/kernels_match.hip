@@ -109,7 +109,7 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   // bin order are the reference's visiting order, so this key reproduces its
   // strict-< first-minimum rule (matcher.cpp:264).  SAD <= 8160 < 2^13.
   uint32_t best_key = 0xFFFFFFFFu;
-  auto consider = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) {
+  auto make_key = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
     const us2 t = as_us2(uv2) - lo2;
     const us2 m = __builtin_elementwise_min(t, span2);
     const bool out = as_u32(t) != as_u32(m);
@@ -121,8 +121,15 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     sad = sad4(a1.y, b1.y, sad);
     sad = sad4(a1.z, b1.z, sad);
     sad = sad4(a1.w, b1.w, sad);
-    const uint32_t key = out ? 0xFFFFFFFFu : ((sad << 19) | (uint32_t)p);
-    best_key = min(best_key, key);
+    return out ? 0xFFFFFFFFu : ((sad << 19) | (uint32_t)p);
+  };
+  auto consider = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) {
+    best_key = min(best_key, make_key(uv2, b0, b1, p));
+  };
+  // two candidates per update: min(best, kA, kB) is one v_min3_u32
+  auto consider2 = [&](uint32_t uvA, const uint4 &a0_, const uint4 &a1_, uint32_t uvB, const uint4 &b0_, const uint4 &b1_, int32_t p) {
+    const uint32_t kA = make_key(uvA, a0_, a1_, p), kB = make_key(uvB, b0_, b1_, p + 1);
+    best_key = min(min(kA, kB), best_key);
   };
 #if VH_MATCH_LDS
   // Candidate stream through a wave-private LDS chunk: lane j of the wave fetches
@@ -148,7 +155,8 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
       int32_t j = 0;
       for (; j + 4 <= mcnt; j += 4) {
 #pragma unroll
-        for (int32_t k = 0; k < 4; k++) consider(wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], pc + j + k);
+        for (int32_t k = 0; k < 4; k += 2)
+          consider2(wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
       }
       for (; j < mcnt; j++) consider(wU[j], wD[2 * j], wD[2 * j + 1], pc + j);
     }
