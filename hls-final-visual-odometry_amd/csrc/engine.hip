@@ -177,6 +177,7 @@ struct Group {
     sets = VhSets{};
     sets.cap = cap;
     sets.binsize = p.match_binsize;
+    sets.inv_binsize = (uint32_t)(((1ull << 32) + p.match_binsize - 1) / p.match_binsize);
     sets.ubn = (dims[0] + p.match_binsize - 1) / p.match_binsize;  // ceil(W/binsize), matcher.cpp:282-283
     sets.vbn = (dims[1] + p.match_binsize - 1) / p.match_binsize;
     sets.nbins = 4 * sets.ubn * sets.vbn;

@@ -455,6 +455,24 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   __syncthreads();
   if (chunk == g.nchunks - 1 && tid == 0) count[set] = base + total;
 
+  // phase A2: bin histogram + per-bin staging + row histogram, one lane per
+  // feature.  Kept out of the descriptor loop below: a returning atomic inside
+  // it serialised one L2 round trip per loop trip.  createIndexVector's bin
+  // (matcher.cpp:208-212) and the (class, v) row; the arbitrary arrival order of
+  // the slots is undone by bin_sort.
+  for (int32_t f = tid; f < total; f += 256) {
+    const int32_t fi = base + f;
+    if (fi >= cap) break;
+    const uint32_t e = sList[f];
+    const int32_t uu = (int32_t)(e & 0x3FFF) * g.scale, vv = (int32_t)((e >> 14) & 0x3FFF) * g.scale, c = e >> 28;
+    const int32_t ubin = s.binsize == 1 ? uu : (int32_t)__umulhi((uint32_t)uu, s.inv_binsize);
+    const int32_t vbin = s.binsize == 1 ? vv : (int32_t)__umulhi((uint32_t)vv, s.inv_binsize);
+    const int32_t b = (c * s.ubn + min(ubin, s.ubn - 1)) * s.vbn + min(vbin, s.vbn - 1);
+    const int32_t slot = atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
+    if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = fi;
+    atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], 1);
+  }
+
   // phase B: 16 lanes per feature, lane k = sample point k
   const int32_t grp = tid >> 4, k = tid & 15;
   const int32_t dx = c_desc_dx[k], dy = c_desc_dy[k];
@@ -472,10 +490,14 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
         // each 5-byte row segment comes from two aligned dwords; the row sums are
         // byte dot products (v_dot4_u32_u8)
         const int32_t x0 = u + dx - 2, o8 = (x0 & 3) * 8;
-        const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (x0 & ~3);
+        // 32-bit byte offsets from the (wave-uniform) image base: images are < 2^28 bytes
+        const uint32_t off0 = (uint32_t)((v + dy - 2) * g.bplm + (x0 & ~3));
         uint32_t lo[5], hi[5];
 #pragma unroll
-        for (int32_t r = 0; r < 5; r++) { lo[r] = *(const uint32_t *)(p + (int64_t)r * g.bplm); hi[r] = *(const uint32_t *)(p + (int64_t)r * g.bplm + 4); }
+        for (int32_t r = 0; r < 5; r++) {
+          const uint8_t *pr = I + (off0 + (uint32_t)(r * g.bplm));
+          lo[r] = *(const uint32_t *)pr; hi[r] = *(const uint32_t *)(pr + 4);
+        }
 #pragma unroll
         for (int32_t r = 0; r < 5; r++) {
           const uint32_t w = (uint32_t)(((uint64_t)hi[r] << 32 | lo[r]) >> o8);  // bytes x0..x0+3
@@ -519,16 +541,6 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     else word = lo | (hi << 16);
     const int32_t fi = base + f;
     if (live && k < 12 && fi < cap) out[(int64_t)fi * 12 + k] = (int32_t)word;
-    if (live && k == 12 && fi < cap) {
-      // createIndexVector's bin (matcher.cpp:208-212) and the (class, v) row of this
-      // feature: histogram + slot in one integer atomic; the arbitrary arrival
-      // order is undone by bin_sort
-      const int32_t uu = u * g.scale, vv = v * g.scale;
-      const int32_t b = (c * s.ubn + min(uu / s.binsize, s.ubn - 1)) * s.vbn + min(vv / s.binsize, s.vbn - 1);
-      const int32_t slot = atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
-      if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = fi;
-      atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], 1);
-    }
   }
 }
 

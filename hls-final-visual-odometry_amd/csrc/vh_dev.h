@@ -70,6 +70,7 @@ struct VhSets {
   int4 *tiles;       // [set][max_tiles] {q0, q1, class, ub}
   int32_t *tile_cnt; // [set]
   int32_t cap, nbins, ubn, vbn, binsize, max_tiles;
+  uint32_t inv_binsize;  // ceil(2^32 / binsize): x / binsize == __umulhi(x, inv_binsize) for 0 <= x < 2^18
   int32_t W, H;      // dims_c of the matcher (full resolution)
   int32_t stage_cap;   // max features of one class in one bin for features of this detector (geometry bound)
   int32_t tile_span; // bins per tile group: vbn (one (class,u-bin) column) or ubn*vbn (a whole class)
