@@ -473,35 +473,48 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], 1);
   }
 
-  // phase B: 16 lanes per feature, lane k = sample point k
+  // phase B: 16 lanes per feature, lane k = sample point k; two features per lane
+  // and loop trip so that both features' row loads are in flight together (the
+  // loop is bound by the load round trip, not by arithmetic)
   const int32_t grp = tid >> 4, k = tid & 15;
   const int32_t dx = c_desc_dx[k], dy = c_desc_dy[k];
   int32_t *__restrict__ out = feat + (int64_t)set * cap * 12;
-  for (int32_t f0 = 0; f0 < total; f0 += 16) {
-    const int32_t f = f0 + grp;
-    const bool live = f < total;
-    const uint32_t e = sList[live ? f : 0];
-    const int32_t u = e & 0x3FFF, v = (e >> 14) & 0x3FFF, c = e >> 28;
-    // 5x5 Sobel pair at (u+dx, v+dy): du = smooth_y (x) deriv_x, dv = deriv_y (x) smooth_x
-    // (filter.cpp:288-318 column pass, :132-171 / :79-127 row passes)
-    int32_t a_du = 0, a_dv = 0;
-    if (live) {
+  for (int32_t f0 = 0; f0 < total; f0 += 32) {
+    int32_t fs[2], us[2], vs[2], cs[2];
+    bool lives[2];
+    uint32_t lo[2][5], hi[2][5];
+    int32_t o8s[2];
+#pragma unroll
+    for (int32_t h = 0; h < 2; h++) {
+      fs[h] = f0 + 16 * h + grp;
+      lives[h] = fs[h] < total;
+      const uint32_t e = sList[lives[h] ? fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
+      us[h] = e & 0x3FFF; vs[h] = (e >> 14) & 0x3FFF; cs[h] = e >> 28;
       if (ALIGNED) {
-        // each 5-byte row segment comes from two aligned dwords; the row sums are
-        // byte dot products (v_dot4_u32_u8)
-        const int32_t x0 = u + dx - 2, o8 = (x0 & 3) * 8;
-        // 32-bit byte offsets from the (wave-uniform) image base: images are < 2^28 bytes
-        const uint32_t off0 = (uint32_t)((v + dy - 2) * g.bplm + (x0 & ~3));
-        uint32_t lo[5], hi[5];
+        // each 5-byte row segment comes from two aligned dwords; 32-bit byte offsets
+        // from the (wave-uniform) image base: images are < 2^28 bytes
+        const int32_t x0 = us[h] + dx - 2;
+        o8s[h] = (x0 & 3) * 8;
+        const uint32_t off0 = (uint32_t)((vs[h] + dy - 2) * g.bplm + (x0 & ~3));
 #pragma unroll
         for (int32_t r = 0; r < 5; r++) {
           const uint8_t *pr = I + (off0 + (uint32_t)(r * g.bplm));
-          lo[r] = *(const uint32_t *)pr; hi[r] = *(const uint32_t *)(pr + 4);
+          lo[h][r] = *(const uint32_t *)pr; hi[h][r] = *(const uint32_t *)(pr + 4);
         }
+      }
+    }
+#pragma unroll
+    for (int32_t h = 0; h < 2; h++) {
+      const int32_t u = us[h], v = vs[h];
+      // 5x5 Sobel pair at (u+dx, v+dy): du = smooth_y (x) deriv_x, dv = deriv_y (x) smooth_x
+      // (filter.cpp:288-318 column pass, :132-171 / :79-127 row passes)
+      int32_t a_du = 0, a_dv = 0;
+      if (ALIGNED) {
 #pragma unroll
         for (int32_t r = 0; r < 5; r++) {
-          const uint32_t w = (uint32_t)(((uint64_t)hi[r] << 32 | lo[r]) >> o8);  // bytes x0..x0+3
-          const int32_t ee = (hi[r] >> o8) & 0xFF;                                 // byte x0+4
+          const uint32_t w = (uint32_t)(((uint64_t)hi[h][r] << 32 | lo[h][r]) >> o8s[h]);  // bytes x0..x0+3
+          const int32_t ee = (hi[h][r] >> o8s[h]) & 0xFF;                                   // byte x0+4
+          // row sums as byte dot products (v_dot4_u32_u8)
           const int32_t rowS = (int32_t)__builtin_amdgcn_udot4(w, 0x04060401u, (uint32_t)ee, false);
           const int32_t rowD = (int32_t)__builtin_amdgcn_udot4(w, 0x00000201u, 0u, false) -
                                (int32_t)__builtin_amdgcn_udot4(w, 0x02000000u, (uint32_t)ee, false);
@@ -514,9 +527,9 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
         const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (u + dx - 2);
 #pragma unroll
         for (int32_t r = 0; r < 5; r++) {
-          const int32_t a = p[0], b = p[1], cc = p[2], d = p[3], ee = p[4];
-          const int32_t rowD = a + 2 * b - 2 * d - ee;
-          const int32_t rowS = a + 4 * b + 6 * cc + 4 * d + ee;
+          const int32_t a = p[0], b = p[1], cc = p[2], dd = p[3], ee = p[4];
+          const int32_t rowD = a + 2 * b - 2 * dd - ee;
+          const int32_t rowS = a + 4 * b + 6 * cc + 4 * dd + ee;
           const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
           const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
           a_du += sw * rowD;
@@ -524,23 +537,23 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
           p += g.bplm;
         }
       }
+      // arithmetic >>7, +128, unsigned saturation (filter.cpp:114-115,124 / :159-160,168)
+      const uint32_t du = (uint32_t)min(255, max(0, (a_du >> 7) + 128));
+      const uint32_t dv = (uint32_t)min(255, max(0, (a_dv >> 7) + 128));
+      const uint32_t pair = du | (dv << 8);
+      // lane L<4 writes the header word, lane 4+j the descriptor dword j = pair[2j] | pair[2j+1]<<16
+      const int32_t lane = tid & 63, gbase = lane & ~15;
+      const int32_t j = (k >= 4) ? (k - 4) : 0;
+      const uint32_t plo = __shfl(pair, gbase + 2 * j), phi = __shfl(pair, gbase + 2 * j + 1);
+      uint32_t word;
+      if (k == 0) word = (uint32_t)(u * g.scale);
+      else if (k == 1) word = (uint32_t)(v * g.scale);
+      else if (k == 2) word = 0;  // val is zeroed on packing (matcher.cpp:667)
+      else if (k == 3) word = (uint32_t)cs[h];
+      else word = plo | (phi << 16);
+      const int32_t fi = base + fs[h];
+      if (lives[h] && k < 12 && fi < cap) out[(int64_t)fi * 12 + k] = (int32_t)word;
     }
-    // arithmetic >>7, +128, unsigned saturation (filter.cpp:114-115,124 / :159-160,168)
-    const uint32_t du = (uint32_t)min(255, max(0, (a_du >> 7) + 128));
-    const uint32_t dv = (uint32_t)min(255, max(0, (a_dv >> 7) + 128));
-    const uint32_t pair = du | (dv << 8);
-    // lane L<4 writes the header word, lane 4+j the descriptor dword j = pair[2j] | pair[2j+1]<<16
-    const int32_t lane = tid & 63, gbase = lane & ~15;
-    const int32_t j = (k >= 4) ? (k - 4) : 0;
-    const uint32_t lo = __shfl(pair, gbase + 2 * j), hi = __shfl(pair, gbase + 2 * j + 1);
-    uint32_t word;
-    if (k == 0) word = (uint32_t)(u * g.scale);
-    else if (k == 1) word = (uint32_t)(v * g.scale);
-    else if (k == 2) word = 0;  // val is zeroed on packing (matcher.cpp:667)
-    else if (k == 3) word = (uint32_t)c;
-    else word = lo | (hi << 16);
-    const int32_t fi = base + f;
-    if (live && k < 12 && fi < cap) out[(int64_t)fi * 12 + k] = (int32_t)word;
   }
 }
 
