@@ -3,9 +3,11 @@
 // Replaces Matcher::createIndexVector (reference src/matcher.cpp:194-214).
 // The reference keeps one std::vector<int32_t> per bin, filled in ascending
 // feature order.  Here a feature set is *reordered* into bin order once
-// (counting sort: histogram -> scan -> fill -> per-bin order restore) and kept
-// as structure-of-arrays (s_uv, s_idx, s_desc), so that the matcher streams
-// candidates of a bin range as one contiguous, coalesced segment.
+// (counting sort: histogram + per-bin staging [in emit_features for detected
+// features, bin_hist/bin_fill for caller-supplied ones] -> scan -> per-bin
+// order restore) and kept as structure-of-arrays (s_uv, s_idx, s_desc), so that
+// the matcher streams candidates of a bin range as one contiguous, coalesced
+// segment; a second copy ordered by (class, v) serves the 1-d stereo search.
 //
 // Bin numbering here is u-bin major, (c*ubn+ub)*vbn+vb, so that the order
 // "u_bin outer, v_bin inner, list position innermost" in which

@@ -7,16 +7,23 @@
 //                                          src/matcher.cpp:470-514)
 //   the packing loop of computeFeatures   (reference src/matcher.cpp:663-671)
 //
-// Design (HBM-bound integer work, no MFMA):
-//   detect_nms    one workgroup per tile of NMS blocks: the image tile (+halo)
-//                 is staged in LDS once, the blob and checkerboard responses
-//                 are produced into LDS by a separable sliding-window pass and
-//                 never touch HBM, NMS runs on the LDS tile (one lane per NMS
-//                 block) and leaves 8 bytes per block (4 x u16 position codes).
+// Design (integer work, no MFMA; VALU/LDS-issue bound):
+//   detect_nms    one workgroup per tile of 32x8 NMS blocks: the image tile
+//                 (+halo) is staged in LDS once, the blob and checkerboard
+//                 responses are produced into LDS by a separable sliding-window
+//                 pass and never touch HBM; NMS runs on the LDS tile: block
+//                 extrema per lane, then "candidate == minimum of its clipped
+//                 (2n+1)^2 window" via a packed vertical window-min/max pass --
+//                 equivalent to the reference's per-candidate dominance scan --
+//                 and leaves 8 bytes per block (4 x u16 position codes).
+//                 detect_nms_fast<N> (nms_n 1..4, 4-byte aligned rows) is the
+//                 compile-time specialised form; detect_nms_kernel is the
+//                 generic one (any nms_n, any stride) with the literal scan.
 //   emit_features ordered compaction of those codes (reference output order:
-//                 block row-major, class ascending), then the 32-byte
-//                 descriptor of each survivor is computed straight from the
-//                 image (16 lanes per feature, one sample point each): the
+//                 block row-major, class ascending), bin/row histograms and
+//                 per-bin staging (first half of createIndexVector), then the
+//                 32-byte descriptor of each survivor is computed straight from
+//                 the image (16 lanes per feature, one sample point each): the
 //                 Sobel planes the reference materialises are never written.
 #include "vh_dev.h"
 

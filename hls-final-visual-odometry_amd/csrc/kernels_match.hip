@@ -8,13 +8,15 @@
 //    is a pure function of (query feature, candidate set), so here every pass
 //    of a chain is evaluated for ALL features of its query set at once
 //    (`match`), and the chains are then followed by table look-ups (`chain`).
-//  * Mapping: one LANE per QUERY, one wavefront per tile of <= 64 bin-ordered
-//    queries of one (class, u-bin) column.  The candidate stream is then
-//    wave-uniform: all 64 lanes walk the same bin range in the same order, the
-//    candidate record is fetched once per wave (scalar/broadcast load) and the
-//    SAD is 8 v_sad_u8 per lane with no cross-lane reduction at all.  Because
-//    positions in bin order ARE the reference's visiting order, its first-minimum
-//    tie-break (strict `<`, src/matcher.cpp:264) is simply "keep the earlier".
+//  * Mapping: one LANE per QUERY, one wavefront per tile of <= 64 consecutive
+//    bin-ordered queries (of one class; of one (class, u-bin) column when the v
+//    window does not span the image).  The candidate stream is then wave-uniform:
+//    all 64 lanes walk the same bin range, candidates are staged 64 at a time in
+//    a wave-private LDS chunk and broadcast-read (VH_MATCH_LDS=0: scalar loads
+//    instead), and the SAD is 8 v_sad_u8 per lane with no cross-lane reduction at
+//    all.  Positions in bin order ARE the reference's visiting order, so its
+//    first-minimum tie-break (strict `<`, src/matcher.cpp:264) is the minimum of
+//    the key (SAD << 19 | position), whatever order candidates arrive in.
 //  * Each lane applies the reference's accept test on its own window
 //    (src/matcher.cpp:249); the wave only walks the union of its lanes' bin
 //    ranges (src/matcher.cpp:237-240), which never changes a lane's result
