@@ -32,9 +32,6 @@
 #ifndef VH_MATCH_LDS
 #define VH_MATCH_LDS 1
 #endif
-#ifndef VH_SB
-#define VH_SB 4
-#endif
 
 namespace {
 
