@@ -110,7 +110,8 @@ int32_t vh_set_intrinsics(vh_matcher *m, double f, double cu, double cv, double 
 int32_t vh_push_back(vh_matcher *m, const uint8_t *I1, const uint8_t *I2,
                      const int32_t dims[3], int32_t replace);
 /* Same, images already resident in device memory (e.g. a torch tensor's
- * data_ptr); asynchronous on the handle's stream. */
+ * data_ptr); asynchronous (the images must stay valid until vh_synchronize or
+ * the next vh_get_*). */
 int32_t vh_push_back_device(vh_matcher *m, const void *dI1, const void *dI2,
                             const int32_t dims[3], int32_t replace);
 
@@ -133,8 +134,12 @@ int32_t vh_get_matches(vh_matcher *m, vh_p_match *out, int32_t cap, int32_t *n);
 int32_t vh_get_features(vh_matcher *m, int32_t which, int32_t *out12, int32_t cap, int32_t *n);
 /* Block until everything queued on the handle's stream has finished. */
 int32_t vh_synchronize(vh_matcher *m);
-/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * handle's own.  Pass NULL to return to the internal stream. */
+/* Order this handle's work after a caller-owned hipStream_t (e.g. the stream
+ * that produces the device images, torch's current stream): every pushBack
+ * first waits for what that stream has been given so far.  The work itself runs
+ * on the handle's internal streams (detection of frame t+1 overlaps matching of
+ * frame t); results are complete after vh_synchronize / vh_get_*.  NULL = no
+ * external ordering. */
 int32_t vh_set_stream(vh_matcher *m, void *hip_stream);
 
 /* ---- stateless primitives (private members of the reference's Matcher) -- */
@@ -187,7 +192,9 @@ int32_t vh_group_create(const vh_params *p, int32_t device, int32_t n_streams,
 void vh_group_destroy(vh_group *g);
 int32_t vh_group_streams(const vh_group *g);
 /* Device-resident images: stream s reads dI1 + s*stride_bytes (and dI2 + ...;
- * dI2 may be NULL).  Asynchronous on the group's stream. */
+ * dI2 may be NULL).  Asynchronous: returns once the work is queued; the images
+ * must stay valid until the detection has run (vh_group_synchronize, or the
+ * next vh_group_get_*). */
 int32_t vh_group_push_back_device(vh_group *g, const void *dI1, const void *dI2,
                                   int64_t stride_bytes, const int32_t dims[3],
                                   int32_t replace);
