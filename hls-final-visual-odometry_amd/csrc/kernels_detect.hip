@@ -331,50 +331,59 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
       }
     }
     __syncthreads();
-    // (b) one lane per NMS block
+    // (b) one lane per NMS block, branch-free (selects, unconditional reads)
     uint32_t cmin = VH_NO_CODE, cmax = VH_NO_CODE;
-    if (have_block) {
+    {
       const int16_t *b = F + fy * T::FP + fx;
       int32_t vn = b[0], vx = vn, pn = 0, px = 0;
 #pragma unroll
       for (int32_t j = 0; j < N1; j++) {
 #pragma unroll
         for (int32_t i = 0; i < N1; i++) {
-          const int32_t cur = b[j * T::FP + i];
-          if (cur < vn) { vn = cur; pn = (j << 6) | i; } else if (cur > vx) { vx = cur; px = (j << 6) | i; }  // first extremum wins
+          if (i == 0 && j == 0) continue;
+          const int32_t cur = b[j * T::FP + i], kk = (j << 6) | i;
+          const bool lt = cur < vn, gt = !lt && cur > vx;  // `else if`: first extremum wins (matcher.cpp:397-405)
+          vn = lt ? cur : vn; pn = lt ? kk : pn;
+          vx = gt ? cur : vx; px = gt ? kk : px;
         }
       }
-      if (vn <= -g.tau) {  // threshold (matcher.cpp:427,451)
-        const int32_t dy = pn >> 6, dx = pn & 63;
-        const int16_t *v = sVmin + (fy + dy - N) * T::FP;
-        int32_t m = v[min(fx + dx - N, xlim)];
+      // candidate == extremum of its clipped (2N+1)^2 window?  (vertical part precomputed)
+      const int16_t *vmn = sVmin + (fy + (pn >> 6) - N) * T::FP;
+      const int16_t *vmx = sVmax + (fy + (px >> 6) - N) * T::FP;
+      const int32_t cn = fx + (pn & 63), cx_ = fx + (px & 63);
+      int32_t wn = vmn[min(cn - N, xlim)], wx = vmx[min(cx_ - N, xlim)];
 #pragma unroll
-        for (int32_t k = -N + 1; k <= N; k++) m = min(m, (int32_t)v[min(fx + dx + k, xlim)]);
-        if (m >= vn) cmin = (uint32_t)pn;
+      for (int32_t k = -N + 1; k <= N; k++) {
+        wn = min(wn, (int32_t)vmn[min(cn + k, xlim)]);
+        wx = max(wx, (int32_t)vmx[min(cx_ + k, xlim)]);
       }
-      if (vx >= g.tau) {  // (matcher.cpp:439,463)
-        const int32_t dy = px >> 6, dx = px & 63;
-        const int16_t *v = sVmax + (fy + dy - N) * T::FP;
-        int32_t m = v[min(fx + dx - N, xlim)];
-#pragma unroll
-        for (int32_t k = -N + 1; k <= N; k++) m = max(m, (int32_t)v[min(fx + dx + k, xlim)]);
-        if (m <= vx) cmax = (uint32_t)px;
-      }
+      // threshold (matcher.cpp:427,439,451,463) and dominance
+      if (have_block && vn <= -g.tau && wn >= vn) cmin = (uint32_t)pn;
+      if (have_block && vx >= g.tau && wx <= vx) cmax = (uint32_t)px;
     }
     codes[2 * plane] = cmin;
     codes[2 * plane + 1] = cmax;
     if (plane == 0) __syncthreads();  // scratch planes are rewritten for f2
   }
 
-  // 4. 8 bytes per block + the per-chunk survivor count
+  // 4. 8 bytes per block + the per-chunk survivor counts.  The counts are first
+  //    accumulated in LDS and flushed with one global atomic per (workgroup,
+  //    chunk): one atomic per block put ~8 k same-address atomics per image on 48
+  //    counters and cost half of this kernel's time.
+  __shared__ int32_t sChunk[16];  // a tile's 8 block rows span < 16 chunks of 1024 blocks (nbx <= 2048 checked by the launcher)
+  const int32_t chunk_lo = (by0 * g.nbx + bx0) / VH_CHUNK;
+  if (tid < 16) sChunk[tid] = 0;
+  __syncthreads();
   if (have_block) {
     int32_t cnt = 0;
 #pragma unroll
     for (int32_t c = 0; c < 4; c++) cnt += codes[c] != VH_NO_CODE ? 1 : 0;
     const int32_t blk = by * g.nbx + bx;
     rec[(int64_t)id * g.nblocks + blk] = (uint64_t)(codes[0] | (codes[1] << 16)) | ((uint64_t)(codes[2] | (codes[3] << 16)) << 32);
-    if (cnt) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + blk / VH_CHUNK], cnt);
+    if (cnt) atomicAdd(&sChunk[blk / VH_CHUNK - chunk_lo], cnt);
   }
+  __syncthreads();
+  if (tid < 16 && sChunk[tid]) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + chunk_lo + tid], sChunk[tid]);
 }
 
 // ------------------------------------------------------------- emit_features
@@ -618,7 +627,7 @@ void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipS
 void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, int32_t *chunk_count,
                           hipStream_t st) {
   if (g.nblocks <= 0) return;
-  if (images_dword_aligned(im, g) && g.n >= 1 && g.n <= 4) {
+  if (images_dword_aligned(im, g) && g.n >= 1 && g.n <= 4 && g.nbx <= 2048) {
     dim3 grid((g.nbx + 31) / 32, (g.nby + 7) / 8, im.S * im.ncam);
     switch (g.n) {
       case 1: hipLaunchKernelGGL(detect_nms_fast_kernel<1>, grid, dim3(256), 0, st, im, g, rec, chunk_count); break;
