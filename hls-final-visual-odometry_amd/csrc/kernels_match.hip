@@ -25,6 +25,7 @@
 #include "vh_dev.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #ifndef VH_FLOW_LDS_PAD_DEFAULT
 #define VH_FLOW_LDS_PAD_DEFAULT 18000
 #endif
@@ -108,10 +109,17 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   // bin order are the reference's visiting order, so this key reproduces its
   // strict-< first-minimum rule (matcher.cpp:264).  SAD <= 8160 < 2^13.
   uint32_t best_key = 0xFFFFFFFFu;
-  auto make_key = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
-    const us2 t = as_us2(uv2) - lo2;
-    const us2 m = __builtin_elementwise_min(t, span2);
-    const bool out = as_u32(t) != as_u32(m);
+  // UTEST=false: the candidate's whole u-bin column lies inside every lane's u
+  // window (wave-uniform fact established per column), so only v is tested.
+  auto make_key = [&](auto utest, uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
+    bool out;
+    if (decltype(utest)::value) {
+      const us2 t = as_us2(uv2) - lo2;
+      const us2 m = __builtin_elementwise_min(t, span2);
+      out = as_u32(t) != as_u32(m);
+    } else {
+      out = (uint32_t)((int32_t)(uv2 >> 16) - v_lo) > (uint32_t)(2 * rv);
+    }
     uint32_t sad = sad4(a0.x, b0.x, 0);
     sad = sad4(a0.y, b0.y, sad);
     sad = sad4(a0.z, b0.z, sad);
@@ -123,13 +131,16 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     return out ? 0xFFFFFFFFu : ((sad << 19) | (uint32_t)p);
   };
   auto consider = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) {
-    best_key = min(best_key, make_key(uv2, b0, b1, p));
+    best_key = min(best_key, make_key(std::true_type{}, uv2, b0, b1, p));
   };
   // two candidates per update: min(best, kA, kB) is one v_min3_u32
-  auto consider2 = [&](uint32_t uvA, const uint4 &a0_, const uint4 &a1_, uint32_t uvB, const uint4 &b0_, const uint4 &b1_, int32_t p) {
-    const uint32_t kA = make_key(uvA, a0_, a1_, p), kB = make_key(uvB, b0_, b1_, p + 1);
+  auto consider2 = [&](auto utest, uint32_t uvA, const uint4 &a0_, const uint4 &a1_, uint32_t uvB, const uint4 &b0_, const uint4 &b1_, int32_t p) {
+    const uint32_t kA = make_key(utest, uvA, a0_, a1_, p), kB = make_key(utest, uvB, b0_, b1_, p + 1);
     best_key = min(min(kA, kB), best_key);
   };
+  // columns whose pixel range [ub*bs, ub*bs+bs-1] is inside EVERY lane's u window
+  const int32_t ULO_MAX = __builtin_amdgcn_readfirstlane(wave_max(valid ? u_lo : -0x40000000));
+  const int32_t UHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(valid ? u_hi : 0x40000000));
 #if VH_MATCH_LDS
   // Candidate stream through a wave-private LDS chunk: lane j of the wave fetches
   // candidate p+j (coalesced 36 B per lane), the chunk is then consumed with
@@ -152,10 +163,18 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
       wU[lane] = gu; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
       int32_t j = 0;
-      for (; j + 4 <= mcnt; j += 4) {
+      if (ub * s.binsize >= ULO_MAX && ub * s.binsize + s.binsize - 1 <= UHI_MIN) {
+        for (; j + 4 <= mcnt; j += 4) {
 #pragma unroll
-        for (int32_t k = 0; k < 4; k += 2)
-          consider2(wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
+          for (int32_t k = 0; k < 4; k += 2)
+            consider2(std::false_type{}, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
+        }
+      } else {
+        for (; j + 4 <= mcnt; j += 4) {
+#pragma unroll
+          for (int32_t k = 0; k < 4; k += 2)
+            consider2(std::true_type{}, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
+        }
       }
       for (; j < mcnt; j++) consider(wU[j], wD[2 * j], wD[2 * j + 1], pc + j);
     }
