@@ -204,8 +204,7 @@ struct Group {
     if ((rc = dmalloc(&sets.row_start, ns * (nrow + 1), true))) return rc;
     if ((rc = dmalloc(&sets.row_hist, ns * nrow, true))) return rc;
     if ((rc = dmalloc(&sets.row_cursor, ns * nrow, true))) return rc;
-    if ((rc = dmalloc(&sets.r_meta, ns * cap, false))) return rc;
-    if ((rc = dmalloc(&sets.r_desc, ns * cap * 8, false))) return rc;
+    if ((rc = dmalloc(&sets.r_pos, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.tiles, ns * sets.max_tiles, false))) return rc;
     if ((rc = dmalloc(&sets.tile_cnt, ns, true))) return rc;
     if ((rc = dmalloc(&d_rec, 2 * (size_t)S * std::max(g.nblocks, 1), false))) return rc;

@@ -232,10 +232,12 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   const int32_t nrow = 4 * s.H;
   const int32_t *__restrict__ qrs = s.row_start + (int64_t)qset * (nrow + 1);
   const int32_t *__restrict__ crs = s.row_start + (int64_t)cset * (nrow + 1);
-  const uint2 *__restrict__ qmeta = s.r_meta + (int64_t)qset * s.cap;
-  const uint4 *__restrict__ qdesc = (const uint4 *)(s.r_desc + (int64_t)qset * s.cap * 8);
-  const uint2 *__restrict__ cmeta = s.r_meta + (int64_t)cset * s.cap;
-  const uint4 *__restrict__ cdesc = (const uint4 *)(s.r_desc + (int64_t)cset * s.cap * 8);
+  const int32_t *__restrict__ qpos = s.r_pos + (int64_t)qset * s.cap;
+  const uint32_t *__restrict__ quv = s.s_uv + (int64_t)qset * s.cap;
+  const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
+  const int32_t *__restrict__ cpos = s.r_pos + (int64_t)cset * s.cap;
+  const uint32_t *__restrict__ cuv = s.s_uv + (int64_t)cset * s.cap;
+  const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
   const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
   const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
   // tile -> (class, query range): classes are contiguous in row order
@@ -256,8 +258,10 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const int32_t q = q0 + lane;
     const bool valid = q < q1;
     const int32_t ql = valid ? q : q0;
-    const uint2 qm = qmeta[ql];
-    const uint4 a0 = qdesc[2 * (int64_t)ql], a1 = qdesc[2 * (int64_t)ql + 1];
+    // row order holds bin positions; the records are gathered from the bin-ordered arrays
+    const int32_t qp = qpos[ql];
+    const uint2 qm = make_uint2(quv[qp], (uint32_t)qp);
+    const uint4 a0 = qdesc[2 * (int64_t)qp], a1 = qdesc[2 * (int64_t)qp + 1];
     const int32_t u1 = qm.x & 0xFFFF, v1 = qm.x >> 16;
     // window: u1 +- radius, v1 +- disp_tolerance; packed accept test as in the flow search
     const us2 lo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
@@ -270,8 +274,9 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     for (int32_t rc = r0; rc < r1; rc += 64) {
       const int32_t mcnt = min(64, r1 - rc);
       const int32_t rl = min(rc + lane, r1 - 1);
-      const uint2 gm = cmeta[rl];
-      const uint4 g0 = cdesc[2 * (int64_t)rl], g1 = cdesc[2 * (int64_t)rl + 1];
+      const int32_t cp = cpos[rl];
+      const uint2 gm = make_uint2(cuv[cp], (uint32_t)cp);
+      const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
       wM[lane] = gm; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave

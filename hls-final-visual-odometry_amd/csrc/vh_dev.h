@@ -21,8 +21,7 @@
 //   row_start [set][4*H+1]   int32   CSR over (class, v) rows: the stereo search
 //                                    (v window of +-disp_tolerance) walks one
 //                                    contiguous row range per query
-//   r_meta    [set][cap]     uint2   {u | v<<16, bin-order position} in row order
-//   r_desc    [set][cap][8]  uint32  descriptor in row order
+//   r_pos     [set][cap]     int32   row order -> bin-order position
 //   rec       [image][nblocks] u64   per NMS block 4 x u16 position codes
 //   best      [stream][pass][cap] int32  findMatch result for every query
 //   matches   [stream][mcap] p_match (48 B, src/matcher.h:89-104)
@@ -65,8 +64,7 @@ struct VhSets {
   int32_t *row_start;  // [set][4*H+1]
   int32_t *row_hist;   // [set][4*H]
   int32_t *row_cursor; // [set][4*H]
-  uint2 *r_meta;       // [set][cap] {u | v<<16, position in bin order}
-  uint32_t *r_desc;    // [set][cap][8]
+  int32_t *r_pos;      // [set][cap] bin-order position of the feature at each row-order position
   int4 *tiles;       // [set][max_tiles] {q0, q1, class, ub}
   int32_t *tile_cnt; // [set]
   int32_t cap, nbins, ubn, vbn, binsize, max_tiles;
