@@ -411,7 +411,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   int32_t *__restrict__ feat = s.feat;
   int32_t *__restrict__ count = s.count;
   const int32_t cap = s.cap;
-  __shared__ uint32_t sList[4 * VH_CHUNK];  // u | v<<14 | c<<28 (matching-resolution coords)
+  __shared__ uint32_t sList[4 * VH_CHUNK + 1];  // u | v<<14 | c<<28 (matching-resolution coords); last word = sink for empty slots
   __shared__ int32_t sWave[4];
   __shared__ int32_t sBase;
 
@@ -432,17 +432,18 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const int32_t base = sBase;
   __syncthreads();
 
-  // phase A: each lane owns 4 consecutive blocks
-  uint64_t codes[4];
+  // phase A: each lane owns 4 consecutive blocks; the four 16-bit codes of a
+  // block are handled as two dwords so every extract is one 32-bit op
+  uint32_t clo[4], chi[4];
   int32_t mine = 0;
 #pragma unroll
   for (int32_t k = 0; k < 4; k++) {
     const int32_t blk = chunk * VH_CHUNK + tid * 4 + k;
-    uint64_t c = ~0ull;
-    if (blk < g.nblocks) c = rec[(int64_t)id * g.nblocks + blk];
-    codes[k] = c;
-#pragma unroll
-    for (int32_t q = 0; q < 4; q++) mine += (((c >> (16 * q)) & 0xFFFF) != VH_NO_CODE) ? 1 : 0;
+    uint2 c = make_uint2(~0u, ~0u);
+    if (blk < g.nblocks) c = reinterpret_cast<const uint2*>(rec)[(int64_t)id * g.nblocks + blk];
+    clo[k] = c.x;
+    chi[k] = c.y;
+    mine += ((c.x & 0xFFFFu) != VH_NO_CODE) + ((c.x >> 16) != VH_NO_CODE) + ((c.y & 0xFFFFu) != VH_NO_CODE) + ((c.y >> 16) != VH_NO_CODE);
   }
   const int32_t incl = wave_incl_scan(mine);
   if ((tid & 63) == 63) sWave[tid >> 6] = incl;
@@ -453,17 +454,23 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   int32_t pos = woff + incl - mine;
   {
     // position code = (row in block) << 6 | (column in block); block coordinates
-    // advance incrementally (one division per lane, not one per block and code)
+    // advance incrementally (one division per lane, not one per block and code).
+    // Appends are branch-free: an empty slot is written to the sink word.
     const int32_t blk0 = chunk * VH_CHUNK + tid * 4;
     int32_t by = blk0 / g.nbx, bx = blk0 - by * g.nbx;
+    const uint32_t org = (uint32_t)(g.n + VH_MARGIN) * ((1u << 14) + 1u);
 #pragma unroll
     for (int32_t k = 0; k < 4; k++) {
-      const int32_t px = g.n + VH_MARGIN + bx * n1, py = g.n + VH_MARGIN + by * n1;
+      const uint32_t pxy = org + (uint32_t)(bx * n1) + ((uint32_t)(by * n1) << 14);  // u | v<<14 of the block corner
 #pragma unroll
       for (int32_t q = 0; q < 4; q++) {
-        const uint32_t pc = (uint32_t)(codes[k] >> (16 * q)) & 0xFFFF;
-        if (pc != VH_NO_CODE)
-          sList[pos++] = (uint32_t)(px + (pc & 63)) | ((uint32_t)(py + (pc >> 6)) << 14) | ((uint32_t)q << 28);
+        const uint32_t w = (q < 2) ? clo[k] : chi[k];
+        const uint32_t pc = (q & 1) ? (w >> 16) : (w & 0xFFFFu);
+        const bool ok = pc != VH_NO_CODE;
+        // (pc & 63) lands in the u field, (pc >> 6) in the v field
+        const uint32_t e = pxy + (pc & 63u) + ((pc >> 6) << 14) + ((uint32_t)q << 28);
+        sList[ok ? pos : 4 * VH_CHUNK] = e;
+        pos += ok ? 1 : 0;
       }
       if (++bx == g.nbx) { bx = 0; by++; }
     }
