@@ -36,10 +36,10 @@ METHOD_FLOW, METHOD_STEREO, METHOD_QUAD = 0, 1, 2
 ABI_SYMBOLS = (
     "vh_abi_version", "vh_device_count", "vh_error_string", "vh_last_error", "vh_default_params",
     "vh_create", "vh_create_ex", "vh_destroy", "vh_set_intrinsics", "vh_push_back", "vh_push_back_device",
-    "vh_match_features", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
+    "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
     "vh_set_stream", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_push_back_device",
-    "vh_group_push_back", "vh_group_match_features", "vh_group_get_matches", "vh_group_get_features",
+    "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
 )
@@ -170,8 +170,11 @@ class Matcher:
     getMatches, same argument meaning, plus getFeatures for the parity checks."""
 
     def __init__(self, param: Params | None = None, device: int = 0, max_features: int = 0,
-                 max_matches: int = 0):
+                 max_matches: int = 0, outlier_removal: bool = True):
         self.param = param if param is not None else Params.default()
+        # matchFeatures ends with removeOutliers as the reference's does (src/matcher.cpp:108);
+        # False gives the bare Matcher::matching result
+        self.outlier_removal = bool(outlier_removal)
         h = C.c_void_p()
         _check(_lib().vh_create_ex(C.byref(self.param), device, max_features, max_matches, C.byref(h)), "vh_create")
         self._h = h
@@ -210,6 +213,13 @@ class Matcher:
         if Tr_delta is not None:
             tr = np.ascontiguousarray(Tr_delta, dtype=np.float64).reshape(16)
         _check(_lib().vh_match_features(self._h, int(method), _ptr(tr)), "vh_match_features")
+        if self.outlier_removal:
+            self.removeOutliers()
+
+    def removeOutliers(self):
+        """removeOutliers (src/remove_outliers.cpp:4-94), which the reference's matchFeatures
+        runs right after matching (src/matcher.cpp:108); host side, flow and quad matches."""
+        _check(_lib().vh_remove_outliers(self._h), "vh_remove_outliers")
 
     def bucketFeatures(self, max_features: int, bucket_width: float, bucket_height: float):
         _check(_lib().vh_bucket_features(self._h, int(max_features), float(bucket_width), float(bucket_height)),
@@ -278,6 +288,10 @@ class StreamGroup:
 
     def matchFeatures(self, method: int):
         _check(_lib().vh_group_match_features(self._h, int(method)), "vh_group_match_features")
+
+    def removeOutliers(self, host_threads: int = 0):
+        """Matcher.removeOutliers for every stream, on `host_threads` host workers (0: all)."""
+        _check(_lib().vh_group_remove_outliers(self._h, int(host_threads)), "vh_group_remove_outliers")
 
     def getMatches(self, stream: int) -> np.ndarray:
         n = C.c_int32(0)
@@ -389,6 +403,14 @@ def match_all_prior(param: Params, dims, m1, m2, u_: float, v_: float, flow: boo
     _check(_lib().vh_match_all_prior(C.byref(param), device, _dims(dims), _ptr(m1), n1, _ptr(m2), n2,
                                      1 if flow else 0, float(u_), float(v_), _ptr(best)), "vh_match_all_prior")
     return best[:n1]
+
+
+def remove_outliers(pm) -> np.ndarray:
+    """removeOutliers (reference src/remove_outliers.cpp:4-94) on p_match records; host only."""
+    pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE).copy()
+    n = C.c_int32(0)
+    _check(_lib().vh_remove_outliers_pm(_ptr(pm), len(pm), C.byref(n)), "vh_remove_outliers_pm")
+    return pm[:n.value].copy()
 
 
 def match(param: Params, dims, method: int, m1p=None, m2p=None, m1c=None, m2c=None, device: int = 0, cap=None):

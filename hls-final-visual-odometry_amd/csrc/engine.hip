@@ -9,12 +9,14 @@
 #include "../../include/viso_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -84,8 +86,11 @@ struct Group {
   std::vector<void *> allocs;
 
   int32_t last_method = -1;
-  bool bucketed = false;
-  std::vector<vh_p_match> host_matches;  // stream 0 only, after vh_bucket_features
+  // streams whose current matches were post-processed on the host
+  // (vh_remove_outliers / vh_bucket_features): served from here until the next step
+  std::vector<std::vector<vh_p_match>> host_matches;
+  std::vector<uint8_t> host_filtered;
+  void drop_host_matches() { std::fill(host_filtered.begin(), host_filtered.end(), 0); }
 
   bool prof = false;
   std::map<std::string, ProfEntry> prof_entries;
@@ -220,7 +225,8 @@ struct Group {
     if (p.half_resolution)
       if ((rc = dmalloc(&d_half, 2 * (size_t)S * g.bplm * g.Hm, false))) return rc;
     allocated = true;
-    pair_cur = 0; pair_prev = 1; frames = 0; epoch = 0; last_method = -1; bucketed = false;
+    pair_cur = 0; pair_prev = 1; frames = 0; epoch = 0; last_method = -1;
+    host_matches.assign((size_t)S, {}); host_filtered.assign((size_t)S, 0);
     for (int k = 0; k < 3; k++) ev_read_valid[k] = false;
     ev_post_valid[0] = ev_post_valid[1] = false; match_seq = 0;
     // every slot starts "detected" (empty): matches may wait on any of them
@@ -280,7 +286,7 @@ struct Group {
       pair_cur = fresh;
     }
     frames++;
-    bucketed = false; last_method = -1;
+    drop_host_matches(); last_method = -1;
     const int32_t set0 = pair_cur * 2 * S, nsets = 2 * S;
     // order after the caller's stream (image producers) and after the last match
     // that still reads the slot we are about to overwrite
@@ -395,7 +401,7 @@ struct Group {
     // both slots stay in use until this point of the post stream
     VH_HIP(hipEventRecord(ev_read[pair_cur], ps)); ev_read_valid[pair_cur] = true;
     VH_HIP(hipEventRecord(ev_read[pair_prev], ps)); ev_read_valid[pair_prev] = true;
-    last_method = method; bucketed = false;
+    last_method = method; drop_host_matches();
     return VH_OK;
   }
 
@@ -403,10 +409,10 @@ struct Group {
     if (!n || s < 0 || s >= S || capo < 0 || (capo > 0 && !out)) return VH_ERR_INVALID_ARG;
     *n = 0;
     if (!allocated || last_method < 0) return VH_OK;
-    if (bucketed && s == 0) {
-      *n = (int32_t)host_matches.size();
+    if (host_filtered[s]) {
+      *n = (int32_t)host_matches[s].size();
       const int32_t k = std::min(*n, capo);
-      if (k) memcpy(out, host_matches.data(), sizeof(vh_p_match) * (size_t)k);
+      if (k) memcpy(out, host_matches[s].data(), sizeof(vh_p_match) * (size_t)k);
       return *n > capo ? VH_ERR_CAPACITY : VH_OK;
     }
     int32_t cnt = 0;
@@ -452,8 +458,53 @@ struct Group {
     if (nm) {
       VH_HIP(hipMemcpyAsync(nm, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
       VH_HIP(hipStreamSynchronize(post_stream));
+      for (int32_t s = 0; s < S; s++)
+        if (host_filtered[s]) nm[s] = (int32_t)host_matches[s].size();
     }
     return VH_OK;
+  }
+
+  // Bring stream s's current matches to the host (no-op if already there).
+  int32_t fetch_matches(int32_t s) {
+    if (s < 0 || s >= S) return VH_ERR_INVALID_ARG;
+    if (!allocated || last_method < 0) return VH_ERR_STATE;
+    if (host_filtered[s]) return VH_OK;
+    int32_t n = 0;
+    int32_t rc = get_matches(s, nullptr, 0, &n);
+    if (rc != VH_OK && rc != VH_ERR_CAPACITY) return rc;
+    if (n > mcap) return VH_ERR_CAPACITY;
+    std::vector<vh_p_match> pm((size_t)n);
+    if (n && (rc = get_matches(s, pm.data(), n, &n))) return rc;
+    host_matches[s].swap(pm);
+    host_filtered[s] = 1;
+    return VH_OK;
+  }
+
+  // removeOutliers (remove_outliers.cpp:4-94) on streams [0, S): host work, one
+  // stream per task, `threads` workers.  Stereo records carry no previous-frame
+  // position (u1p = -1), so the flow vote only applies to flow and quad matches.
+  int32_t remove_outliers(int32_t s_lo, int32_t s_hi, int32_t threads) {
+    if (!allocated || last_method < 0) return VH_ERR_STATE;
+    if (last_method == VH_METHOD_STEREO) return VH_OK;
+    for (int32_t s = s_lo; s < s_hi; s++) {
+      const int32_t rc = fetch_matches(s);
+      if (rc) return rc;
+    }
+    std::atomic<int32_t> next_stream(s_lo), failed(0);
+    const auto work = [&]() {
+      for (int32_t s = next_stream++; s < s_hi; s = next_stream++) {
+        std::vector<vh_p_match> &pm = host_matches[s];
+        int32_t kept = 0;
+        if (vh_remove_outliers_pm(pm.data(), (int32_t)pm.size(), &kept) != VH_OK) { failed = 1; continue; }
+        pm.resize((size_t)kept);
+      }
+    };
+    const int32_t nw = std::max(1, std::min(threads, s_hi - s_lo));
+    std::vector<std::thread> pool;
+    for (int32_t w = 1; w < nw; w++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    return failed ? VH_ERR_INVALID_ARG : VH_OK;
   }
 
   // Load caller-supplied feature records into a role's set and index it.
@@ -724,16 +775,19 @@ int32_t vh_match_features(vh_matcher *m, int32_t method, const double *Tr_delta1
 int32_t vh_bucket_features(vh_matcher *m, int32_t max_features, float bucket_width, float bucket_height) {
   Group *gq = (Group *)m; ENTER(gq);
   if (max_features < 1 || !(bucket_width > 0) || !(bucket_height > 0)) return VH_ERR_INVALID_ARG;
-  int32_t n = 0;
-  int32_t rc = gq->get_matches(0, nullptr, 0, &n);
-  if (rc != VH_OK && rc != VH_ERR_CAPACITY) return rc;
-  if (n > gq->mcap) return VH_ERR_CAPACITY;
-  std::vector<vh_p_match> pm((size_t)n);
-  if (n && (rc = gq->get_matches(0, pm.data(), n, &n))) return rc;
-  bucket_host(pm, max_features, bucket_width, bucket_height);
-  gq->host_matches.swap(pm);
-  gq->bucketed = true;
+  const int32_t rc = gq->fetch_matches(0);
+  if (rc) return rc == VH_ERR_STATE ? VH_OK : rc;  // nothing matched yet: nothing to bucket
+  bucket_host(gq->host_matches[0], max_features, bucket_width, bucket_height);
   return VH_OK;
+}
+int32_t vh_remove_outliers(vh_matcher *m) {
+  Group *gq = (Group *)m; ENTER(gq);
+  return gq->remove_outliers(0, 1, 1);
+}
+int32_t vh_group_remove_outliers(vh_group *g, int32_t host_threads) {
+  Group *gq = (Group *)g; ENTER(gq);
+  if (host_threads < 1) host_threads = (int32_t)std::max(1u, std::thread::hardware_concurrency());
+  return gq->remove_outliers(0, gq->S, host_threads);
 }
 int32_t vh_get_matches(vh_matcher *m, vh_p_match *out, int32_t cap, int32_t *n) {
   Group *gq = (Group *)m; ENTER(gq);

@@ -118,8 +118,21 @@ int32_t vh_push_back_device(vh_matcher *m, const void *dI1, const void *dI2,
 /* Matcher::matchFeatures(method, Tr_delta) (src/matcher.h:128,
  * src/matcher.cpp:93-111) with the stock Matcher::matching behind it
  * (src/matcher.cpp:274-344).  Tr_delta16 (row-major 4x4) is accepted and
- * ignored, as the reference does.  Does not run removeOutliers. */
+ * ignored, as the reference does.  The reference's matchFeatures goes on to
+ * call removeOutliers (src/matcher.cpp:108); here that is the separate
+ * vh_remove_outliers below, which the C++ shim calls for you. */
 int32_t vh_match_features(vh_matcher *m, int32_t method, const double *Tr_delta16);
+
+/* removeOutliers (src/remove_outliers.cpp:4-94 over src/delaunator.cpp:183-407):
+ * Delaunay-neighbour flow-consistency vote on the current matches, host side
+ * (a sequential float triangulation whose result depends on its
+ * visiting order -- see csrc/outliers.cpp).  Filters flow and quad matches;
+ * stereo matches (no previous-frame position) are left as they are.
+ * VH_ERR_STATE before the first vh_match_features. */
+int32_t vh_remove_outliers(vh_matcher *m);
+/* The same on caller-owned records, in place, order preserved; *n_out = count
+ * kept.  Pure host function: needs no device. */
+int32_t vh_remove_outliers_pm(vh_p_match *pm, int32_t n, int32_t *n_out);
 
 /* Matcher::bucketFeatures (src/matcher.h:132, src/matcher.cpp:140-187):
  * host-side post-processing of the current matches, LFSR shuffle included. */
@@ -202,6 +215,9 @@ int32_t vh_group_push_back_device(vh_group *g, const void *dI1, const void *dI2,
 int32_t vh_group_push_back(vh_group *g, const uint8_t *I1, const uint8_t *I2,
                            int64_t stride_bytes, const int32_t dims[3], int32_t replace);
 int32_t vh_group_match_features(vh_group *g, int32_t method);
+/* vh_remove_outliers for every stream of the group, `host_threads` workers
+ * (<= 0: one per hardware thread).  Host-bound: a few ms per stream. */
+int32_t vh_group_remove_outliers(vh_group *g, int32_t host_threads);
 int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32_t cap,
                              int32_t *n);
 int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_t *out12,

@@ -16,7 +16,11 @@
 //    stock SSE Matcher::computeFeatures / matching semantics are reproduced
 //    bit for bit, NOT the 1024x284-only HLS restatement the reference's
 //    pushBack/matchFeatures currently call (finding 2);
-//  * matchFeatures does not run removeOutliers (a separate, host-side step);
+//  * matchFeatures ends with removeOutliers like the reference's
+//    (src/matcher.cpp:108), host side and bit-identical to it; set
+//    `outlier_removal = false` for the bare Matcher::matching result.  Stereo
+//    matches (method 1, absent from the reference) are never filtered: its
+//    vote compares flows, which stereo records do not carry;
 //  * errors that the reference ignores (capacity overrun, bad dims) are
 //    reported on std::cerr and leave the match list empty instead of
 //    corrupting memory.
@@ -84,7 +88,7 @@ class Matcher {
   };
 
   // constructor (src/matcher.cpp:32-41); `device` selects the GPU of this stream
-  explicit Matcher(parameters param, int32_t device = 0) : param(param), handle(0) {
+  explicit Matcher(parameters param, int32_t device = 0) : outlier_removal(true), param(param), handle(0) {
     static_assert(sizeof(parameters) == sizeof(vh_params), "parameters must mirror vh_params");
     static_assert(sizeof(p_match) == sizeof(vh_p_match) && sizeof(p_match) == 48, "p_match must be 48 bytes");
     vh_params p;
@@ -117,8 +121,9 @@ class Matcher {
   void matchFeatures(int32_t method, Matrix *Tr_delta = 0) {
     (void)Tr_delta;
     if (!handle) return;
-    const int32_t rc = vh_match_features(handle, method, 0);
-    if (rc != VH_OK && rc != VH_ERR_STATE) report("matchFeatures", rc);
+    int32_t rc = vh_match_features(handle, method, 0);
+    if (rc != VH_OK && rc != VH_ERR_STATE) { report("matchFeatures", rc); return; }
+    if (rc == VH_OK && outlier_removal && (rc = vh_remove_outliers(handle)) != VH_OK) report("removeOutliers", rc);
   }
 
   // src/matcher.h:132, src/matcher.cpp:140-187
@@ -156,6 +161,9 @@ class Matcher {
   }
 
   bool ok() const { return handle != 0; }
+
+  // matchFeatures finishes with removeOutliers (src/matcher.cpp:108) unless cleared
+  bool outlier_removal;
 
  private:
   Matcher(const Matcher &);             // one handle per camera stream

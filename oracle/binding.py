@@ -177,6 +177,22 @@ class Oracle:
                                         C.c_float(bw), C.c_float(bh))
         return pm[:n].copy()
 
+    def delaunay(self, xy):
+        """-> (triangle corners [t,3], deepest flip stack)"""
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        cap = 6 * len(xy) + 16
+        tri = np.zeros(cap, np.int32); depth = C.c_int32(0)
+        self.lib.vo_delaunay.restype = C.c_int32
+        n = self.lib.vo_delaunay(_ptr(xy), C.c_int32(len(xy)), _ptr(tri), C.c_int32(cap), C.byref(depth))
+        return tri[:n].reshape(-1, 3).copy(), depth.value
+
+    def remove_outliers(self, pm):
+        """-> (kept matches, deepest flip stack)"""
+        pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE).copy()
+        depth = C.c_int32(0)
+        n = self.lib.vo_remove_outliers(_ptr(pm), C.c_int32(len(pm)), C.byref(depth))
+        return pm[:n].copy(), depth.value
+
 
 class Reference:
     """The reference's own CPU/SSE code (oracle/_ref/libviso_ref.so)."""
@@ -254,4 +270,18 @@ class Reference:
         pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE).copy()
         n = self.lib.ref_bucket_features(C.byref(params), _ptr(pm), len(pm), max_features, float(bw), float(bh))
         assert n >= 0
+        return pm[:n].copy()
+
+    def delaunay(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        cap = 6 * len(xy) + 16
+        tri = np.zeros(cap, np.int32)
+        n = self.lib.ref_delaunay(_ptr(xy), C.c_int32(len(xy)), _ptr(tri), C.c_int32(cap))
+        assert n >= 0, n
+        return tri[:n].reshape(-1, 3).copy()
+
+    def remove_outliers(self, pm):
+        pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE).copy()
+        n = self.lib.ref_remove_outliers(_ptr(pm), C.c_int32(len(pm)))
+        assert n >= 0, n
         return pm[:n].copy()

@@ -115,6 +115,41 @@ def main():
         print(f"bucket({mf},{bw},{bh}): {len(r['p_match'])} -> {len(out)}")
     np.savez_compressed(os.path.join(GOLDEN, "bucket_1024x284.npz"), **bk)
 
+    # removeOutliers + the Delaunay sweep under it (src/remove_outliers.cpp:4-94,
+    # src/delaunator.cpp:183-407).  Inputs: reference flow matches with a seeded
+    # tenth of the flows disturbed, so that the vote has something to remove.
+    rng = np.random.default_rng(2024)
+    ol = {}
+    for name in ("small_default", "small_bin20_r60", "dense_gain4"):
+        W, H, blur, gain, seed, pan, over = CASES[name]
+        p, dims, r = run_case(ref, ob, synth, W, H, blur, gain, seed, pan, over)
+        pm = r["p_match"].copy()
+        k = rng.choice(len(pm), max(1, len(pm) // 10), replace=False)
+        pm["u1p"][k] += rng.integers(-25, 26, len(k)).astype(np.float32)
+        pm["v1p"][k] += rng.integers(-9, 10, len(k)).astype(np.float32)
+        out = ref.remove_outliers(pm)
+        ol[name + "__in"] = pm
+        ol[name + "__kept"] = np.flatnonzero(np.isin(pm["i1c"], out["i1c"])).astype(np.int32)
+        assert pm[ol[name + "__kept"]].tobytes() == out.tobytes()
+        print(f"removeOutliers({name}): {len(pm)} -> {len(out)}")
+    pts = rng.choice(640 * 200, 700, replace=False)
+    xy = np.stack([pts % 640, pts // 640], 1).astype(np.float32)
+    ol["delaunay__xy"] = xy
+    ol["delaunay__tri"] = ref.delaunay(xy)
+    # KITTI-sized, hash only
+    W, H, blur, gain, seed, pan, over = HASH_CASES["kitti_1241x376"]
+    p, dims, r = run_case(ref, ob, synth, W, H, blur, gain, seed, pan, over)
+    pm = r["p_match"].copy()
+    k = rng.choice(len(pm), len(pm) // 10, replace=False)
+    pm["u1p"][k] += rng.integers(-25, 26, len(k)).astype(np.float32)
+    out = ref.remove_outliers(pm)
+    ol["kitti__disturbed"] = k.astype(np.int32)
+    ol["kitti__du"] = (pm["u1p"][k] - r["p_match"]["u1p"][k]).astype(np.int32)
+    ol["kitti__n_out"] = np.int32(len(out))
+    ol["kitti__fnv_out"] = np.uint64(o.fnv(out))
+    print(f"removeOutliers(kitti): {len(pm)} -> {len(out)} fnv={int(ol['kitti__fnv_out']):016x}")
+    np.savez_compressed(os.path.join(GOLDEN, "outliers.npz"), **ol)
+
 
 if __name__ == "__main__":
     main()

@@ -203,6 +203,35 @@ int32_t ref_bucket_features(const HParams *hp, void *pm, int32_t n, int32_t max_
   return h.m->p_matched_2_cnt;
 }
 
+/* removeOutliers (src/remove_outliers.cpp:4-94), the step Matcher::matchFeatures
+ * runs right after matching (src/matcher.cpp:108).  Works on a POINT_L-sized
+ * copy because the reference's signature is p_match[POINT_L]; its working set
+ * (Delaunator + copy + support counters, about 2 MB) lives on the stack. */
+int32_t ref_remove_outliers(void *pm, int32_t n) {
+  if (n > POINT_L) return -1;
+  Matcher::p_match *buf = new Matcher::p_match[POINT_L];
+  memcpy(buf, pm, sizeof(Matcher::p_match) * (size_t)n);
+  int32_t cnt = n;
+  removeOutliers(buf, cnt);
+  memcpy(pm, buf, sizeof(Matcher::p_match) * (size_t)cnt);
+  delete[] buf;
+  return cnt;
+}
+
+/* delaunator::Delaunator (src/delaunator.cpp:183-407) on its own: returns the
+ * number of triangle corners written (3 per triangle). */
+int32_t ref_delaunay(const float *xy, int32_t n, int32_t *tri, int32_t cap) {
+  if (n > POINT_L || n < 3) return -1;
+  delaunator::Delaunator *d = new delaunator::Delaunator();
+  for (int32_t i = 0; i < n; i++) d->read_point(xy[2 * i], xy[2 * i + 1]);
+  d->delaunat();
+  const int32_t cnt = d->triangles_cnt;
+  if (cnt > cap) { delete d; return -2; }
+  memcpy(tri, d->triangles, sizeof(int32_t) * (size_t)cnt);
+  delete d;
+  return cnt;
+}
+
 int32_t ref_sizeof_p_match(void) { return (int32_t)sizeof(Matcher::p_match); }
 int32_t ref_point_l(void) { return POINT_L; }
 

@@ -132,6 +132,18 @@ void vo_match_all(const vo_params *p, const int32_t dims[3],
 int32_t vo_bucket_features(vo_p_match *pm, int32_t n, int32_t max_features,
                            float bucket_width, float bucket_height);
 
+/* [pinned] delaunator::Delaunator::delaunat (src/delaunator.cpp:183-407) on n
+ * points xy = {x0,y0,x1,y1,...}: writes min(result, cap) triangle corners
+ * (3 per triangle, reference order) and returns the corner count.  *max_depth
+ * (nullable) receives the deepest flip stack used; the reference's stack has
+ * 13 slots (delaunator.hpp:13) and is undefined beyond.  See viso_outliers.c. */
+int32_t vo_delaunay(const float *xy, int32_t n, int32_t *tri_out, int32_t cap, int32_t *max_depth);
+
+/* [pinned] removeOutliers (src/remove_outliers.cpp:4-94): Delaunay-neighbour
+ * flow-consistency vote on (u1c,v1c), hard-coded tolerance 5, keep >= 4 votes.
+ * In place, order preserved, returns the new count. */
+int32_t vo_remove_outliers(vo_p_match *pm, int32_t n, int32_t *max_depth);
+
 /* FNV-1a-64 over raw bytes. */
 uint64_t vo_fnv1a64(const void *data, uint64_t nbytes);
 

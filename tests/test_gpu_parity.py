@@ -72,7 +72,7 @@ def test_known_answers_full_size(case, pkg, oracle, gpu):
     z = np.load(os.path.join(GOLDEN, "known_answers.npz"))
     W, H, blur, gain, seed, dx, dy = [int(v) for v in z[case + "__gen"]]
     dims = [W, H, pkg.synth.bytes_per_line(W)]
-    m = pkg.Matcher(pkg.Params.default())
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
     assert m.pushBack(pkg.synth.frame(W, H, 0, 0, blur, gain, seed), None, dims, False)
     assert m.pushBack(pkg.synth.frame(W, H, dx, dy, blur, gain, seed), None, dims, False)
     m.matchFeatures(pkg.METHOD_FLOW)
@@ -135,7 +135,7 @@ def test_matcher_ring_buffer_and_methods(pkg, ob, oracle, gpu):
     p, po = pkg.Params.default(), ob.Params.default()
     seq = pkg.synth.stereo_sequence(W, H, 4, disparity=8, blur=4, seed=21)
     F = [[oracle.compute_features(po, im, dims)[1] for im in pair] for pair in seq]
-    m = pkg.Matcher(p)
+    m = pkg.Matcher(p, outlier_removal=False)
     m.pushBack(seq[0][0], seq[0][1], dims, False)
     # one frame only: previous sets are empty -> no flow/quad matches, stereo works
     m.matchFeatures(pkg.METHOD_QUAD)
@@ -163,7 +163,7 @@ def test_matcher_ring_buffer_and_methods(pkg, ob, oracle, gpu):
 
 
 def test_dimension_mismatch_and_errors(pkg, gpu, capsys):
-    m = pkg.Matcher(pkg.Params.default())
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
     img = np.zeros((50, 64), np.uint8)
     assert m.pushBack(img, None, [64, 50, 32], False) is False  # bpl < width (src/matcher.cpp:59-62)
     assert "Image dimension mismatch" in capsys.readouterr().out
@@ -242,7 +242,7 @@ def test_capacity_errors(pkg, gpu):
     W, H = 320, 160
     dims = [W, H, pkg.synth.bytes_per_line(W)]
     img = pkg.synth.frame(W, H, blur=4, seed=3)
-    m = pkg.Matcher(pkg.Params.default(), max_features=100, max_matches=50)
+    m = pkg.Matcher(pkg.Params.default(), max_features=100, max_matches=50, outlier_removal=False)
     m.pushBack(img, None, dims, False)
     n = C.c_int32(0)
     buf = np.zeros((100, 12), np.int32)
@@ -259,7 +259,7 @@ def test_bucket_features(pkg, ob, oracle, gpu):
     dims = [1024, 284, 1024]
     for key in g.files:
         _, mf, bw, bh = key.split("_")
-        m = pkg.Matcher(pkg.Params.default())
+        m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
         m.pushBack(pkg.synth.frame(1024, 284, 0, 0), None, dims, False)
         m.pushBack(pkg.synth.frame(1024, 284, 5, 1), None, dims, False)
         m.matchFeatures(pkg.METHOD_FLOW)
@@ -272,7 +272,7 @@ def test_bucket_features(pkg, ob, oracle, gpu):
     fp = oracle.compute_features(po, pkg.synth.frame(1241, 376, 0, 0), d2)[1]
     fc = oracle.compute_features(po, pkg.synth.frame(1241, 376, 5, 1), d2)[1]
     want = oracle.bucket_features(oracle.matching(po, d2, 0, m1p=fp, m1c=fc), 2, 50, 50)
-    m = pkg.Matcher(pkg.Params.default())
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
     m.pushBack(pkg.synth.frame(1241, 376, 0, 0), None, d2, False)
     m.pushBack(pkg.synth.frame(1241, 376, 5, 1), None, d2, False)
     m.matchFeatures(0); m.bucketFeatures(2, 50, 50)
@@ -350,7 +350,7 @@ def test_kitti_stereo_quad_full_size(pkg, ob, oracle, gpu):
     dims = [W, H, 1248]
     po = ob.Params.default()
     seq = pkg.synth.stereo_sequence(W, H, 2, disparity=12)
-    m = pkg.Matcher(pkg.Params.default())
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
     for l, r in seq:
         m.pushBack(l, r, dims, False)
     m.matchFeatures(pkg.METHOD_QUAD)
@@ -402,7 +402,7 @@ def test_1080p_all_classes_radius200(pkg, ob, oracle, gpu):
     dims = [W, H, 1920]
     po = ob.Params.default()
     seq = pkg.synth.stereo_sequence(W, H, 2, disparity=10, seed=2)
-    m = pkg.Matcher(pkg.Params.default())
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
     for l, r in seq:
         m.pushBack(l, r, dims, False)
     m.matchFeatures(pkg.METHOD_QUAD)
@@ -427,7 +427,7 @@ def test_4k_dense_small_bins(pkg, ob, oracle, gpu):
     over = {"nms_n": 3, "match_binsize": 25}
     p, po = pkg.Params.default(**over), ob.Params.default(**over)
     Ip = pkg.synth.frame(W, H, 0, 0, seed=3); Ic = pkg.synth.frame(W, H, 5, 1, seed=3)
-    m = pkg.Matcher(p)
+    m = pkg.Matcher(p, outlier_removal=False)
     m.pushBack(Ip, None, dims, False)
     m.pushBack(Ic, None, dims, False)
     m.matchFeatures(pkg.METHOD_FLOW)

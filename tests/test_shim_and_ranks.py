@@ -54,7 +54,7 @@ def test_reference_vo_drivers_build_against_the_shim(tmp_path, pkg):
         objs.append(o)
     subprocess.check_call(["g++", "-o", str(d / "demo")] + objs + LINK)
     syms = subprocess.check_output(["nm", "-C", str(d / "viso_stereo.o")]).decode()
-    for s in ("vh_push_back", "vh_match_features", "vh_bucket_features", "vh_get_matches"):
+    for s in ("vh_push_back", "vh_match_features", "vh_remove_outliers", "vh_bucket_features", "vh_get_matches"):
         assert s in syms  # VisualOdometryStereo::process really goes through the C ABI
 
 
@@ -106,6 +106,7 @@ def test_shim_stereo_loop_matches_oracle(bucket, tmp_path, pkg, ob, oracle, gpu)
             assert n == 0  # no previous pair yet
             continue
         want = oracle.matching(po, dims, 2, F[t - 1][0], F[t - 1][1], F[t][0], F[t][1])
+        want, _ = oracle.remove_outliers(want)  # the shim's matchFeatures ends with it (src/matcher.cpp:108)
         if bucket:
             want = oracle.bucket_features(want, 2, 50, 50)
         assert n == len(want) and n > 50 and got.tobytes() == want.tobytes()

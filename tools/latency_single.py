@@ -12,17 +12,19 @@ bpl = pkg.synth.bytes_per_line(W)
 dims = [W, H, bpl]
 seq = pkg.synth.stereo_sequence(W, H, 8, 12)
 
-m = pkg.Matcher(pkg.Params.default())
-for l, r in seq[:3]:
-    m.pushBack(l, r, dims, False); m.matchFeatures(2); m.getMatches()
-t0 = time.perf_counter(); n = 0
-for rep in range(5):
-    for l, r in seq:
-        m.pushBack(l, r, dims, False); m.matchFeatures(2); pm = m.getMatches(); n += 1
-dt = time.perf_counter() - t0
-print(f"single stream, host images, getMatches every frame (the VisualOdometryStereo::process pattern): "
-      f"{1e3 * dt / n:.3f} ms per pair = {n / dt:.0f} pairs/s, {len(pm)} matches")
-m.close()
+for outlier_removal in (False, True):
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=outlier_removal)
+    for l, r in seq[:3]:
+        m.pushBack(l, r, dims, False); m.matchFeatures(2); m.getMatches()
+    t0 = time.perf_counter(); n = 0
+    for rep in range(5):
+        for l, r in seq:
+            m.pushBack(l, r, dims, False); m.matchFeatures(2); pm = m.getMatches(); n += 1
+    dt = time.perf_counter() - t0
+    print(f"single stream, host images, getMatches every frame (the VisualOdometryStereo::process pattern), "
+          f"removeOutliers {'on (host)' if outlier_removal else 'off'}: "
+          f"{1e3 * dt / n:.3f} ms per pair = {n / dt:.0f} pairs/s, {len(pm)} matches")
+    m.close()
 
 for S in (64, 256):
     g = pkg.StreamGroup(S, pkg.Params.default(), max_features=32768, max_matches=32768)
