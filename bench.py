@@ -31,6 +31,16 @@ import __graft_entry__ as entry  # noqa: E402
 
 METRIC = "stereo frame-pairs/sec (detect+match), KITTI 1241x376; matches bit-exact"
 W, H = 1241, 376
+# BASELINE.json configs: the metric is quoted on "kitti" (cfg-2, the default and the only
+# driver-run line); "1080p" (cfg-3) and "4k" (cfg-5) are context runs for DESIGN.md
+WORKLOADS = {
+    "kitti": dict(W=1241, H=376, params={}, streams=256, cap=32768,
+                  label="KITTI 1241x376 stereo quad-match (prev/curr x L/R), default 50x50 bins"),
+    "1080p": dict(W=1920, H=1080, params={}, streams=48, cap=131072,
+                  label="1920x1080 stereo quad-match, default parameters"),
+    "4k": dict(W=3840, H=2160, params={"nms_n": 3, "match_binsize": 25}, streams=12, cap=524287,
+               label="3840x2160 stereo quad-match, nms_n=3, 25x25 bins"),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNELS = ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill", "bin_sort",
            "match_stereo", "match_flow", "chain", "emit_matches")
@@ -55,12 +65,12 @@ def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
     return out, bpl
 
 
-def cpu_baseline(ob, frames, dims, budget_s: float):
+def cpu_baseline(ob, frames, dims, budget_s: float, over=None):
     """The oracle (CPU port of the reference SSE path; flow bit-identical to the
     reference, quad per SURVEY App. A.7) on a bounded sample of the SAME
     workload: stream 0's consecutive stereo pairs, one thread."""
     o = ob.Oracle()
-    p = ob.Params.default()
+    p = ob.Params.default(**(over or {}))
     T = frames.shape[0]
     prev = None
     pairs = 0
@@ -137,14 +147,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", "256")),
-                    help="independent camera streams per GPU, stepped together")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", "0")),
+                    help="independent camera streams per GPU, stepped together (0: the workload's default)")
     ap.add_argument("--frames", type=int, default=8, help="distinct frames per stream kept in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
     args = ap.parse_args()
+    global W, H
+    wl = WORKLOADS[args.workload]
+    W, H = wl["W"], wl["H"]
+    if args.streams <= 0:
+        args.streams = wl["streams"]
     if args.dist_selftest:
         return dist_selftest(args)
 
@@ -170,7 +186,8 @@ def main():
     stride = H * bpl
 
     stream = torch.cuda.current_stream()
-    grp = pkg.StreamGroup(S, pkg.Params.default(), device=local_rank, max_features=32768, max_matches=32768)
+    grp = pkg.StreamGroup(S, pkg.Params.default(**wl["params"]), device=local_rank, max_features=wl["cap"],
+                          max_matches=wl["cap"])
     grp.setStream(stream.cuda_stream)  # orders the group's work after this stream's (the frame upload)
 
     def step(k):
@@ -238,10 +255,11 @@ def main():
                         "algorithmic_bytes_per_launch": S * B_pair, "us_per_launch": prof[dom]["us_per_launch"],
                         "note": "integer SAD search: v_sad_u8 issue-bound, not HBM-bound (DESIGN.md)"}
         out = {
-            "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC if args.workload == "kitti" else f"stereo frame-pairs/sec (detect+match), {W}x{H}; matches bit-exact",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "KITTI 1241x376 stereo quad-match (prev/curr x L/R), default 50x50 bins",
+            "config": {"workload": wl["label"],
                        "streams_per_gpu": S, "frames_in_hbm": T, "features_per_image": float(nfm.mean()),
                        "matches_per_pair": float(nm.mean()), "parallelism": f"{world}x independent stream groups"},
             "roofline": roofline,
@@ -249,12 +267,12 @@ def main():
         }
         if not args.no_cpu:
             ob = entry.load_oracle()
-            rate, n_pairs, secs, results = cpu_baseline(ob, frames_np, dims, args.cpu_seconds)
+            rate, n_pairs, secs, results = cpu_baseline(ob, frames_np, dims, args.cpu_seconds, wl["params"])
             out["cpu_baseline"] = {"value": rate, "unit": "pairs/s", "cores": 1, "kind": "port",
                                    "sample": f"{n_pairs} consecutive stereo pairs of stream 0 (detect 2 images + quad match each), "
                                              f"{secs:.1f} s, oracle/viso_oracle.c single thread"}
             # the oracle as checker: stream 0's last GPU step must equal the CPU result for the same frames
-            o = ob.Oracle(); p = ob.Params.default()
+            o = ob.Oracle(); p = ob.Params.default(**wl["params"])
             prev_t = (last - 1) % T
             f = [o.compute_features(p, frames_np[t_, c, 0], dims)[1] for t_ in (prev_t, last) for c in (0, 1)]
             want = o.matching(p, dims, 2, *f)

@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "vh_abi_version", "vh_device_count", "vh_error_string", "vh_last_error", "vh_default_params",
     "vh_create", "vh_create_ex", "vh_destroy", "vh_set_intrinsics", "vh_push_back", "vh_push_back_device",
     "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
-    "vh_set_stream", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
+    "vh_set_stream", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_push_back_device",
     "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
@@ -110,6 +110,8 @@ def _lib():
             "vh_match_features": [vp, i32, vp], "vh_bucket_features": [vp, i32, f32, f32],
             "vh_get_matches": [vp, vp, i32, vp], "vh_get_features": [vp, i32, vp, i32, vp],
             "vh_synchronize": [vp], "vh_set_stream": [vp, vp],
+            "vh_remove_outliers": [vp], "vh_remove_outliers_pm": [vp, i32, vp], "vh_group_remove_outliers": [vp, i32],
+            "vh_host_alloc": [i32, C.c_size_t, vp], "vh_host_free": [vp],
             "vh_compute_features": [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp],
             "vh_filters": [i32, vp, i32, i32, vp, vp, vp, vp],
             "vh_create_index": [vp, i32, vp, vp, i32, vp, vp],
@@ -157,6 +159,20 @@ def _feat(m):
 def device_count() -> int:
     """Visible HIP devices (0 when there is none)."""
     return max(0, _lib().vh_device_count())
+
+
+def pinned_empty(shape, dtype=np.uint8, device: int = 0) -> np.ndarray:
+    """numpy array over page-locked host memory (vh_host_alloc): image buffers whose
+    upload in pushBack runs at PCIe rate.  Freed when the array is collected."""
+    import weakref
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = C.c_void_p()
+    _check(_lib().vh_host_alloc(int(device), C.c_size_t(max(n, 1)), C.byref(ptr)), "vh_host_alloc")
+    buf = (C.c_uint8 * max(n, 1)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, _lib().vh_host_free, C.c_void_p(ptr.value))
+    return arr
 
 
 def abi_version() -> int:

@@ -72,7 +72,14 @@ struct Group {
   int32_t pair_cur = 0;
   int64_t frames = 0;
 
-  uint8_t *d_stage[2] = {nullptr, nullptr};  // host-image staging, S images each
+  // host-image staging, S images per camera, two slots: the upload of frame t+1
+  // does not wait for the detection of frame t, only for that of frame t-1
+  uint8_t *d_stage_buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  uint8_t *d_stage[2] = {nullptr, nullptr};  // the slot of the last push_host
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  bool ev_stage_valid[2] = {false, false};
+  int32_t stage_slot = 0;
+  hipStream_t copy_stream = nullptr;
   size_t stage_bytes = 0;
   uint8_t *d_half = nullptr;                 // half-resolution images [S*2]
   uint64_t *d_rec = nullptr;
@@ -99,6 +106,8 @@ struct Group {
     release();
     for (int k = 0; k < 3; k++) { if (ev_det[k]) (void)hipEventDestroy(ev_det[k]); if (ev_read[k]) (void)hipEventDestroy(ev_read[k]); }
     if (ev_user) (void)hipEventDestroy(ev_user);
+    for (int k = 0; k < 2; k++) if (ev_stage[k]) (void)hipEventDestroy(ev_stage[k]);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); }
     if (post_stream && own_post) (void)hipStreamDestroy(post_stream);
     if (match_stream && !serial) (void)hipStreamDestroy(match_stream);
@@ -116,6 +125,7 @@ struct Group {
     for (void *q : allocs) (void)hipFree(q);
     allocs.clear();
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0;
+    for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr;
@@ -334,19 +344,36 @@ struct Group {
     if (rc != VH_OK) return rc;
     const size_t isz = (size_t)d[2] * d[1];
     if (stage_bytes < isz * S) {
-      for (int k = 0; k < 2; k++) if ((rc = dmalloc(&d_stage[k], isz * S, false))) return rc;
+      VH_HIP(hipStreamSynchronize(stream));
+      for (int sl = 0; sl < 2; sl++)
+        for (int k = 0; k < 2; k++) if ((rc = dmalloc(&d_stage_buf[sl][k], isz * S, false))) return rc;
       stage_bytes = isz * S;
+      ev_stage_valid[0] = ev_stage_valid[1] = false;
     }
-    VH_HIP(hipStreamSynchronize(stream));  // the previous frame's detection still reads the staging buffers
+    const int32_t sl = stage_slot;
+    stage_slot ^= 1;
+    // the detection that last read this staging slot (two pushes ago) must be done
+    if (ev_stage_valid[sl]) VH_HIP(hipStreamWaitEvent(copy_stream, ev_stage[sl], 0));
     for (int k = 0; k < 2; k++) {
       const uint8_t *src = k ? I2 : I1;
+      d_stage[k] = d_stage_buf[sl][k];
       if (!src) continue;
-      for (int32_t s = 0; s < S; s++)
-        VH_HIP(hipMemcpyAsync(d_stage[k] + isz * s, src + stride * s, isz, hipMemcpyHostToDevice, stream));
+      if (stride == (int64_t)isz) {  // one transfer for all S images
+        VH_HIP(hipMemcpyAsync(d_stage[k], src, isz * S, hipMemcpyHostToDevice, copy_stream));
+      } else {
+        for (int32_t s = 0; s < S; s++)
+          VH_HIP(hipMemcpyAsync(d_stage[k] + isz * s, src + stride * s, isz, hipMemcpyHostToDevice, copy_stream));
+      }
     }
-    // the images are only borrowed for the duration of the call (demo.cpp:250-251)
-    VH_HIP(hipStreamSynchronize(stream));
-    return push_device(d_stage[0], I2 ? d_stage[1] : nullptr, (int64_t)isz, d, replace);
+    // the images are only borrowed for the duration of the call (demo.cpp:250-251);
+    // the copy runs beside the previous step's kernels, the host waits for it here
+    VH_HIP(hipStreamSynchronize(copy_stream));
+    rc = push_device(d_stage[0], I2 ? d_stage[1] : nullptr, (int64_t)isz, d, replace);
+    if (rc == VH_OK) {
+      VH_HIP(hipEventRecord(ev_stage[sl], stream));
+      ev_stage_valid[sl] = true;
+    }
+    return rc;
   }
 
   // ---- match ---------------------------------------------------------------
@@ -623,6 +650,8 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
     ok = hipEventCreateWithFlags(&gq->ev_det[k], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&gq->ev_read[k], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&gq->ev_user, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&gq->ev_stage[k], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&gq->copy_stream, hipStreamNonBlocking) == hipSuccess;
   if (!ok) { t_last_error = "stream/event creation failed"; delete gq; return VH_ERR_HIP; }
   *out = gq;
   return VH_OK;
@@ -796,6 +825,19 @@ int32_t vh_get_matches(vh_matcher *m, vh_p_match *out, int32_t cap, int32_t *n) 
 int32_t vh_get_features(vh_matcher *m, int32_t which, int32_t *out12, int32_t cap, int32_t *n) {
   Group *gq = (Group *)m; ENTER(gq);
   return gq->get_features(0, which, out12, cap, n);
+}
+int32_t vh_host_alloc(int32_t device, size_t bytes, void **out) {
+  if (!out || bytes == 0) return VH_ERR_INVALID_ARG;
+  *out = nullptr;
+  const int32_t rc = select_device(device);
+  if (rc) return rc;
+  VH_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return VH_OK;
+}
+int32_t vh_host_free(void *ptr) {
+  if (!ptr) return VH_OK;
+  VH_HIP(hipHostFree(ptr));
+  return VH_OK;
 }
 int32_t vh_synchronize(vh_matcher *m) { return vh_group_synchronize((vh_group *)m); }
 int32_t vh_set_stream(vh_matcher *m, void *hip_stream) { return vh_group_set_stream((vh_group *)m, hip_stream); }

@@ -19,6 +19,7 @@
 #ifndef VISO_HIP_H
 #define VISO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -114,6 +115,15 @@ int32_t vh_push_back(vh_matcher *m, const uint8_t *I1, const uint8_t *I2,
  * the next vh_get_*). */
 int32_t vh_push_back_device(vh_matcher *m, const void *dI1, const void *dI2,
                             const int32_t dims[3], int32_t replace);
+
+/* Page-locked host memory for image buffers handed to vh_push_back /
+ * vh_group_push_back.  The reference's callers read frames into malloc'd
+ * buffers (src/demo.cpp:107-110) and lend them to pushBack for the call
+ * (src/matcher.cpp:51-91); any host pointer works here too, but uploads from
+ * page-locked memory run at PCIe rate instead of through the driver's bounce
+ * buffer.  Needs a device (VH_ERR_NO_DEVICE otherwise). */
+int32_t vh_host_alloc(int32_t device, size_t bytes, void **out);
+int32_t vh_host_free(void *ptr);
 
 /* Matcher::matchFeatures(method, Tr_delta) (src/matcher.h:128,
  * src/matcher.cpp:93-111) with the stock Matcher::matching behind it

@@ -446,3 +446,32 @@ def test_4k_dense_small_bins(pkg, ob, oracle, gpu):
     bs, lst = pkg.create_index(p, dims, fc)
     bo, lo = oracle.create_index(po, fc, dims)
     assert len(bs) == 4 * 154 * 87 + 1 and np.array_equal(bs, bo) and np.array_equal(lst, lo)
+
+
+@pytest.mark.gpu
+def test_page_locked_host_images_and_staging_slots(pkg, ob, oracle, gpu):
+    """Host images from vh_host_alloc memory (one transfer per camera) and from
+    pageable memory give the same matches over a run long enough to cycle both
+    staging slots and all three ring slots."""
+    W, H, S, T = 320, 160, 3, 6
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, T, disparity=5 + s, blur=4, seed=60 + s) for s in range(S)]
+    ga = pkg.StreamGroup(S, pkg.Params.default())
+    gb = pkg.StreamGroup(S, pkg.Params.default())
+    L = pkg.pinned_empty((S, H, dims[2])); R = pkg.pinned_empty((S, H, dims[2]))
+    po = ob.Params.default()
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(T)] for s in range(S)]
+    for t in range(T):
+        for s in range(S):
+            L[s], R[s] = seqs[s][t]
+        ga.pushBack(L, R, dims, False)
+        L[...] = 0; R[...] = 0  # borrowed for the call only: the engine must not read them afterwards
+        gb.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+        if t == 0:
+            continue
+        ga.matchFeatures(pkg.METHOD_QUAD); gb.matchFeatures(pkg.METHOD_QUAD)
+        for s in range(S):
+            want = oracle.matching(po, dims, 2, F[s][t - 1][0], F[s][t - 1][1], F[s][t][0], F[s][t][1])
+            assert len(want) > 50
+            assert ga.getMatches(s).tobytes() == want.tobytes() and gb.getMatches(s).tobytes() == want.tobytes()
+    ga.close(); gb.close()

@@ -26,10 +26,14 @@ for outlier_removal in (False, True):
           f"{1e3 * dt / n:.3f} ms per pair = {n / dt:.0f} pairs/s, {len(pm)} matches")
     m.close()
 
-for S in (64, 256):
+for S, pinned in ((64, False), (256, False), (256, True)):
     g = pkg.StreamGroup(S, pkg.Params.default(), max_features=32768, max_matches=32768)
     L = [np.ascontiguousarray(np.stack([seq[t][0]] * S)) for t in range(8)]
     R = [np.ascontiguousarray(np.stack([seq[t][1]] * S)) for t in range(8)]
+    if pinned:  # page-locked image buffers (vh_host_alloc)
+        for buf in (L, R):
+            for t in range(8):
+                q = pkg.pinned_empty(buf[t].shape); q[...] = buf[t]; buf[t] = q
     for t in range(3):
         g.pushBack(L[t], R[t], dims, False); g.matchFeatures(2)
     g.synchronize()
@@ -39,5 +43,5 @@ for S in (64, 256):
             g.pushBack(L[t], R[t], dims, False); g.matchFeatures(2); k += 1
     g.synchronize()
     dt = time.perf_counter() - t0
-    print(f"group of {S} streams, HOST images (pageable, synchronous H2D inside pushBack): {S * k / dt:.0f} pairs/s")
+    print(f"group of {S} streams, HOST images ({'page-locked' if pinned else 'pageable'}, H2D inside pushBack): {S * k / dt:.0f} pairs/s")
     g.close()
