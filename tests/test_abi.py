@@ -3,6 +3,7 @@ include/viso_hip.h declares; host-side logic that needs no GPU."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -105,3 +106,35 @@ def test_synth_generator(pkg, oracle):
     assert np.array_equal(seq[0][0][:, 7:200], seq[0][1][:, :193])  # right = left shifted by the disparity
     # SURVEY App. B's FNV variant (offset 1469598103934665603), python vs C
     assert s.fnv1a64(a[:3]) == oracle.fnv(np.ascontiguousarray(a[:3]))
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path, pkg):
+    """include/viso_hip.h is a C header (any FFI can bind it): it must compile as
+    strict C99, and a C program must link against libviso_hip.so and run its
+    host-only entry points without a GPU."""
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "viso_hip.h"
+int main(void) {
+  vh_params p; vh_default_params(&p);
+  if (p.nms_n != 2 || p.match_radius != 200 || sizeof(vh_p_match) != 48) return 1;
+  vh_p_match pm[6]; memset(pm, 0, sizeof pm);
+  for (int i = 0; i < 6; i++) { pm[i].u1c = (float)(10 * i); pm[i].v1c = (float)((i * 7) % 5 * 9); pm[i].u1p = pm[i].u1c + 2; pm[i].v1p = pm[i].v1c; pm[i].i1c = i; }
+  int32_t n = -1;
+  if (vh_remove_outliers_pm(pm, 3, &n) != VH_OK || n != 3) return 2;      /* <= 3 matches: untouched */
+  if (vh_remove_outliers_pm(pm, 6, &n) != VH_OK || n < 0 || n > 6) return 3;
+  if (vh_remove_outliers_pm(pm, 6, NULL) != VH_ERR_INVALID_ARG) return 4;
+  printf("%d %s\n", vh_abi_version(), vh_error_string(VH_ERR_NO_DEVICE));
+  return 0;
+}
+''')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I" + inc, str(src)])
+    exe = str(tmp_path / "host")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-I" + inc, str(src), "-o", exe, "-L" + libdir, "-lviso_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([exe], timeout=60).decode().split()
+    assert int(out[0]) == pkg.abi_version()
