@@ -67,36 +67,63 @@ __global__ void bin_hist_kernel(VhSets s, int32_t set0) {
   }
 }
 
+__device__ __forceinline__ int32_t scan_wave_inclusive(int32_t v) {
+#pragma unroll
+  for (int32_t d = 1; d < 64; d <<= 1) {
+    const int32_t t = __shfl_up(v, d);
+    if ((int32_t)(threadIdx.x & 63) >= d) v += t;
+  }
+  return v;
+}
+
+// Workgroup-wide exclusive scan of load(0..n-1): every element i is handed to
+// emit(i, prefix, value); returns the total.  EPT consecutive elements per lane
+// and trip, a wave scan of the lane sums and one LDS exchange of the
+// VH_SCAN_T/64 wave totals -- two barriers per EPT*VH_SCAN_T elements.
+template <int EPT, class Load, class Emit>
+__device__ __forceinline__ int32_t scan_exclusive(int32_t n, int32_t *sWave, Load load, Emit emit) {
+  const int32_t tid = threadIdx.x, w = tid >> 6;
+  int32_t carry = 0;
+  for (int32_t b0 = 0; b0 < n; b0 += EPT * VH_SCAN_T) {
+    const int32_t b = b0 + EPT * tid;
+    int32_t v[EPT];
+    int32_t mine = 0;
+#pragma unroll
+    for (int32_t k = 0; k < EPT; k++) { v[k] = (b + k < n) ? load(b + k) : 0; mine += v[k]; }
+    const int32_t incl = scan_wave_inclusive(mine);
+    if ((tid & 63) == 63) sWave[w] = incl;
+    __syncthreads();
+    int32_t before = 0, total = 0;
+#pragma unroll
+    for (int32_t k = 0; k < VH_SCAN_T / 64; k++) {
+      const int32_t x = sWave[k];
+      before += (k < w) ? x : 0;
+      total += x;
+    }
+    int32_t run = carry + before + incl - mine;
+#pragma unroll
+    for (int32_t k = 0; k < EPT; k++) {
+      if (b + k < n) emit(b + k, run, v[k]);
+      run += v[k];
+    }
+    carry += total;
+    __syncthreads();  // sWave is rewritten by the next trip
+  }
+  return carry;
+}
+
 // One workgroup per set: exclusive scan of the histogram into bin_start, and
 // the list of query tiles (<= 64 consecutive bin-ordered features of one
 // (class, u-bin) column) the match kernel works through.
 __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t set0) {
-  __shared__ int32_t sPart[VH_SCAN_T];
-  __shared__ int32_t sCarry;
+  __shared__ int32_t sWave[VH_SCAN_T / 64];
   const int32_t set = set0 + blockIdx.x, tid = threadIdx.x;
   const int32_t *__restrict__ hist = s.hist + (int64_t)set * s.nbins;
   int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
-  if (tid == 0) sCarry = 0;
-  __syncthreads();
-  for (int32_t b0 = 0; b0 < s.nbins; b0 += VH_SCAN_T) {
-    const int32_t b = b0 + tid;
-    const int32_t v = (b < s.nbins) ? hist[b] : 0;
-    sPart[tid] = v;
-    __syncthreads();
-    for (int32_t d = 1; d < VH_SCAN_T; d <<= 1) {  // Hillis-Steele inclusive scan
-      const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
-      __syncthreads();
-      sPart[tid] += t;
-      __syncthreads();
-    }
-    const int32_t incl = sPart[tid], carry = sCarry;
-    if (b < s.nbins) bs[b] = carry + incl - v;
-    __syncthreads();
-    if (tid == VH_SCAN_T - 1) sCarry = carry + incl;
-    __syncthreads();
-  }
-  if (tid == 0) bs[s.nbins] = sCarry;
-  __syncthreads();
+  const int32_t nfeat = scan_exclusive<4>(s.nbins, sWave, [&](int32_t b) { return hist[b]; },
+                                       [&](int32_t b, int32_t prefix, int32_t) { bs[b] = prefix; });
+  if (tid == 0) bs[s.nbins] = nfeat;
+  __syncthreads();  // bin_start is read back below by other lanes
 
   // query tiles: <= 64 consecutive bin-ordered queries of one tile group.  A
   // group is one (class, u-bin) column, or -- when the v search window covers
@@ -105,57 +132,25 @@ __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t s
   // almost every wave (column remainders would leave ~25 % of them idle).
   const int32_t ngroup = s.nbins / s.tile_span;
   int4 *__restrict__ tiles = s.tiles + (int64_t)set * s.max_tiles;
-  if (tid == 0) sCarry = 0;
-  __syncthreads();
-  for (int32_t c0 = 0; c0 < ngroup; c0 += VH_SCAN_T) {
-    const int32_t grp = c0 + tid;
-    int32_t q0 = 0, q1 = 0;
-    if (grp < ngroup) { q0 = bs[grp * s.tile_span]; q1 = bs[(grp + 1) * s.tile_span]; }
-    const int32_t nt = (q1 - q0 + 63) >> 6;
-    sPart[tid] = nt;
-    __syncthreads();
-    for (int32_t d = 1; d < VH_SCAN_T; d <<= 1) {
-      const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
-      __syncthreads();
-      sPart[tid] += t;
-      __syncthreads();
-    }
-    const int32_t incl = sPart[tid], carry = sCarry;
-    int32_t t0 = carry + incl - nt;
-    const int32_t cls = (grp * s.tile_span) / (s.ubn * s.vbn);
-    for (int32_t k = 0; k < nt; k++, t0++)
-      if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + 64 * k, min(q1, q0 + 64 * k + 64), cls, 0);
-    __syncthreads();
-    if (tid == VH_SCAN_T - 1) sCarry = carry + incl;
-    __syncthreads();
-  }
-  if (tid == 0) s.tile_cnt[set] = min(sCarry, s.max_tiles);
-  __syncthreads();
+  // one group per lane: the per-group tile writes below then spread over the lanes
+  const int32_t ntile = scan_exclusive<1>(
+      ngroup, sWave,
+      [&](int32_t grp) { return (bs[(grp + 1) * s.tile_span] - bs[grp * s.tile_span] + 63) >> 6; },
+      [&](int32_t grp, int32_t t0, int32_t nt) {
+        const int32_t q0 = bs[grp * s.tile_span], q1 = bs[(grp + 1) * s.tile_span];
+        const int32_t cls = (grp * s.tile_span) / (s.ubn * s.vbn);
+        for (int32_t k = 0; k < nt; k++, t0++)
+          if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + 64 * k, min(q1, q0 + 64 * k + 64), cls, 0);
+      });
+  if (tid == 0) s.tile_cnt[set] = min(ntile, s.max_tiles);
 
   // row index: exclusive scan of the (class, v) histogram
   const int32_t nrow = 4 * s.H;
   const int32_t *__restrict__ rh = s.row_hist + (int64_t)set * nrow;
   int32_t *__restrict__ rs = s.row_start + (int64_t)set * (nrow + 1);
-  if (tid == 0) sCarry = 0;
-  __syncthreads();
-  for (int32_t b0 = 0; b0 < nrow; b0 += VH_SCAN_T) {
-    const int32_t b = b0 + tid;
-    const int32_t v = (b < nrow) ? rh[b] : 0;
-    sPart[tid] = v;
-    __syncthreads();
-    for (int32_t d = 1; d < VH_SCAN_T; d <<= 1) {
-      const int32_t t = (tid >= d) ? sPart[tid - d] : 0;
-      __syncthreads();
-      sPart[tid] += t;
-      __syncthreads();
-    }
-    const int32_t incl = sPart[tid], carry = sCarry;
-    if (b < nrow) rs[b] = carry + incl - v;
-    __syncthreads();
-    if (tid == VH_SCAN_T - 1) sCarry = carry + incl;
-    __syncthreads();
-  }
-  if (tid == 0) rs[nrow] = sCarry;
+  const int32_t nrowfeat = scan_exclusive<4>(nrow, sWave, [&](int32_t r) { return rh[r]; },
+                                          [&](int32_t r, int32_t prefix, int32_t) { rs[r] = prefix; });
+  if (tid == 0) rs[nrow] = nrowfeat;
 }
 
 __global__ void bin_fill_kernel(VhSets s, int32_t set0) {

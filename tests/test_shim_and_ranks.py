@@ -111,3 +111,33 @@ def test_shim_stereo_loop_matches_oracle(bucket, tmp_path, pkg, ob, oracle, gpu)
             want = oracle.bucket_features(want, 2, 50, 50)
         assert n == len(want) and n > 50 and got.tobytes() == want.tobytes()
     assert pos == len(raw)
+
+
+@pytest.mark.gpu
+def test_shim_mono_loop_matches_oracle(tmp_path, pkg, ob, oracle, gpu):
+    """VisualOdometryMono::process pattern (src/viso_mono.cpp:33-39): the mono
+    pushBack overload, flow matching, removeOutliers, bucketing."""
+    exe = build_shim_demo(tmp_path, pkg)
+    W, H, nf = 480, 200, 4
+    bpl = pkg.synth.bytes_per_line(W)
+    seq = pkg.synth.stereo_sequence(W, H, nf, disparity=9, blur=5, seed=78)
+    with open(tmp_path / "frames.bin", "wb") as f:
+        for l, r in seq:
+            f.write(l.tobytes()); f.write(r.tobytes())
+    subprocess.check_call([exe, str(tmp_path / "frames.bin"), str(W), str(H), str(bpl), str(nf), "1",
+                           str(tmp_path / "out.bin"), "1"], timeout=120)
+    raw = open(tmp_path / "out.bin", "rb").read()
+    po = ob.Params.default()
+    dims = [W, H, bpl]
+    F = [oracle.compute_features(po, pair[0], dims)[1] for pair in seq]
+    pos = 0
+    for t in range(nf):
+        n = int(np.frombuffer(raw, np.int32, 1, pos)[0]); pos += 4
+        got = np.frombuffer(raw, pkg.P_MATCH_DTYPE, n, pos); pos += 48 * n
+        if t == 0:
+            assert n == 0
+            continue
+        want, _ = oracle.remove_outliers(oracle.matching(po, dims, 0, m1p=F[t - 1], m1c=F[t]))
+        want = oracle.bucket_features(want, 2, 50, 50)
+        assert n == len(want) and n > 20 and got.tobytes() == want.tobytes()
+    assert pos == len(raw)
