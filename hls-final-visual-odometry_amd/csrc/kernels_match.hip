@@ -111,13 +111,15 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   uint32_t best_key = 0xFFFFFFFFu;
   // UTEST=false: the candidate's whole u-bin column lies inside every lane's u
   // window (wave-uniform fact established per column), so only v is tested.
-  auto make_key = [&](auto utest, uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
-    bool out;
-    if (decltype(utest)::value) {
+  // TEST: 2 = full (u,v) window test, 1 = v only, 0 = none (see the column loop)
+  auto make_key = [&](auto test, uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
+    constexpr int TEST = decltype(test)::value;
+    bool out = false;
+    if (TEST == 2) {
       const us2 t = as_us2(uv2) - lo2;
       const us2 m = __builtin_elementwise_min(t, span2);
       out = as_u32(t) != as_u32(m);
-    } else {
+    } else if (TEST == 1) {
       out = (uint32_t)((int32_t)(uv2 >> 16) - v_lo) > (uint32_t)(2 * rv);
     }
     uint32_t sad = sad4(a0.x, b0.x, 0);
@@ -128,19 +130,26 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     sad = sad4(a1.y, b1.y, sad);
     sad = sad4(a1.z, b1.z, sad);
     sad = sad4(a1.w, b1.w, sad);
-    return out ? 0xFFFFFFFFu : ((sad << 19) | (uint32_t)p);
+    const uint32_t key = (sad << 19) | (uint32_t)p;
+    return (TEST != 0 && out) ? 0xFFFFFFFFu : key;
   };
   auto consider = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) {
-    best_key = min(best_key, make_key(std::true_type{}, uv2, b0, b1, p));
+    best_key = min(best_key, make_key(std::integral_constant<int, 2>{}, uv2, b0, b1, p));
   };
   // two candidates per update: min(best, kA, kB) is one v_min3_u32
-  auto consider2 = [&](auto utest, uint32_t uvA, const uint4 &a0_, const uint4 &a1_, uint32_t uvB, const uint4 &b0_, const uint4 &b1_, int32_t p) {
-    const uint32_t kA = make_key(utest, uvA, a0_, a1_, p), kB = make_key(utest, uvB, b0_, b1_, p + 1);
+  auto consider2 = [&](auto test, uint32_t uvA, const uint4 &a0_, const uint4 &a1_, uint32_t uvB, const uint4 &b0_, const uint4 &b1_, int32_t p) {
+    const uint32_t kA = make_key(test, uvA, a0_, a1_, p), kB = make_key(test, uvB, b0_, b1_, p + 1);
     best_key = min(min(kA, kB), best_key);
   };
   // columns whose pixel range [ub*bs, ub*bs+bs-1] is inside EVERY lane's u window
   const int32_t ULO_MAX = __builtin_amdgcn_readfirstlane(wave_max(valid ? u_lo : -0x40000000));
   const int32_t UHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(valid ? u_hi : 0x40000000));
+  // v-bins [VA0, VA1] whose pixel rows lie inside EVERY lane's v window: in an
+  // interior column their candidates need no accept test at all
+  const int32_t VLO_MAX = __builtin_amdgcn_readfirstlane(wave_max(valid ? v_lo : -0x40000000));
+  const int32_t VHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(valid ? v_hi : 0x40000000));
+  const int32_t VA0 = max(VB0, (max(VLO_MAX, 0) + s.binsize - 1) / s.binsize);
+  const int32_t VA1 = min(VB1, (VHI_MIN + 1) / s.binsize - 1);
 #if VH_MATCH_LDS
   // Candidate stream through a wave-private LDS chunk: lane j of the wave fetches
   // candidate p+j (coalesced 36 B per lane), the chunk is then consumed with
@@ -154,6 +163,10 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const int32_t row = (c * s.ubn + ub) * s.vbn;
     const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
     const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + VB1 + 1]);
+    const bool interior = ub * s.binsize >= ULO_MAX && ub * s.binsize + s.binsize - 1 <= UHI_MIN;
+    // positions of the untested v-bins of this column (empty when VA0 > VA1)
+    const int32_t pa0 = (interior && VA0 <= VA1) ? __builtin_amdgcn_readfirstlane(cbs[row + VA0]) : p1;
+    const int32_t pa1 = (interior && VA0 <= VA1) ? __builtin_amdgcn_readfirstlane(cbs[row + VA1 + 1]) : p1;
     for (int32_t pc = p0; pc < p1; pc += 64) {
       const int32_t mcnt = min(64, p1 - pc);
       const int32_t pl = min(pc + lane, p1 - 1);
@@ -163,17 +176,25 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
       wU[lane] = gu; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
       int32_t j = 0;
-      if (ub * s.binsize >= ULO_MAX && ub * s.binsize + s.binsize - 1 <= UHI_MIN) {
-        for (; j + 4 <= mcnt; j += 4) {
+      if (interior) {
+        // [0, ja): v test, [ja, jb): no test, [jb, mcnt): v test
+        const int32_t ja = min(max(pa0 - pc, 0), mcnt), jb = min(max(pa1 - pc, ja), mcnt);
+        auto run = [&](auto test, int32_t jend) {
+          for (; j + 4 <= jend; j += 4) {
 #pragma unroll
-          for (int32_t k = 0; k < 4; k += 2)
-            consider2(std::false_type{}, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
-        }
+            for (int32_t k = 0; k < 4; k += 2)
+              consider2(test, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
+          }
+          for (; j < jend; j++) best_key = min(best_key, make_key(test, wU[j], wD[2 * j], wD[2 * j + 1], pc + j));
+        };
+        run(std::integral_constant<int, 1>{}, ja);
+        run(std::integral_constant<int, 0>{}, jb);
+        run(std::integral_constant<int, 1>{}, mcnt);
       } else {
         for (; j + 4 <= mcnt; j += 4) {
 #pragma unroll
           for (int32_t k = 0; k < 4; k += 2)
-            consider2(std::true_type{}, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
+            consider2(std::integral_constant<int, 2>{}, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
         }
       }
       for (; j < mcnt; j++) consider(wU[j], wD[2 * j], wD[2 * j + 1], pc + j);
