@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU box: HIP path vs the CPU oracle over random
+image sizes, textures (incl. noise, flat areas, saturated patches) and matcher
+parameters, for a time budget.  A longer, wider version of
+tests/test_gpu_parity.py::test_random_configs_vs_oracle; prints one line per
+failure with everything needed to reproduce it, and a summary.
+
+    python tools/fuzz_parity.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+pkg = entry.load_package()
+ORACLE_ONLY = bool(os.environ.get("FUZZ_ORACLE_ONLY"))  # CPU dry run of the generator and the oracle
+ob = entry.load_oracle()
+oracle = ob.Oracle()
+synth = pkg.synth
+
+
+def texture(rng, W, H, dx, dy, spec):
+    kind, blur, gain, seed, noise = spec
+    img = synth.frame(W, H, dx, dy, blur, gain, seed).copy()
+    if kind == 1:    # sensor noise
+        img = np.clip(img.astype(np.float64) + np.random.default_rng(seed + dx * 131 + dy).normal(0, noise, img.shape), 0, 255).astype(np.uint8)
+    elif kind == 2:  # flat rectangles (ties in the NMS scan) and saturated patches
+        r = np.random.default_rng(seed)
+        for _ in range(6):
+            x0, y0 = int(r.integers(0, max(1, W - 8))), int(r.integers(0, max(1, H - 8)))
+            w, h = int(r.integers(4, max(5, W // 3))), int(r.integers(4, max(5, H // 3)))
+            img[y0:y0 + h, x0:x0 + w] = int(r.choice([0, 255, 128, int(r.integers(0, 256))]))
+    elif kind == 3:  # high-contrast binary texture: large responses, many equal values
+        img = np.where(img > np.median(img), 255, 0).astype(np.uint8)
+    img[:, W:] = 0
+    return np.ascontiguousarray(img)
+
+
+t_end = time.time() + budget
+trial = 0
+fails = 0
+stats = {"features": 0, "matches": 0}
+while time.time() < t_end:
+    rng = np.random.default_rng(seed0 * 100003 + trial)
+    trial += 1
+    small = rng.random() < 0.25
+    W = int(rng.integers(24, 90)) if small else int(rng.integers(90, 900))
+    H = int(rng.integers(24, 70)) if small else int(rng.integers(70, 500))
+    over = {"nms_n": int(rng.integers(1, 7)), "nms_tau": int(rng.integers(1, 120)),
+            "match_binsize": int(rng.integers(5, 160)), "match_radius": int(rng.integers(1, 400)),
+            "match_disp_tolerance": int(rng.integers(0, 6)),
+            "half_resolution": int(rng.random() < 0.3), "multi_stage": int(rng.random() < 0.3)}
+    spec = (int(rng.integers(0, 4)), int(rng.integers(0, 8)), int(rng.integers(1, 5)), int(rng.integers(1, 100000)), float(rng.uniform(0.5, 6)))
+    disp = int(rng.integers(0, 14))
+    p, po = pkg.Params.default(**over), ob.Params.default(**over)
+    dims = [W, H, synth.bytes_per_line(W)]
+    tag = f"trial {trial} seed0 {seed0} W {W} H {H} {over} spec {spec} disp {disp}"
+    try:
+        imgs = []
+        for t in range(2):
+            dx, dy = int(rng.integers(0, 9)) * t, int(rng.integers(0, 6)) * t
+            imgs += [texture(rng, W, H, dx, dy, spec), texture(rng, W, H, dx + disp, dy, spec)]
+        feats = []
+        ok = True
+        for im in imgs:
+            want = oracle.compute_features(po, im, dims)
+            got = want if ORACLE_ONLY else pkg.compute_features(p, im, dims)
+            if not (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])):
+                ok = False
+                print("FAIL features:", tag, len(got[1]), len(want[1]), flush=True)
+                break
+            feats.append(want[1])
+        if ok and ORACLE_ONLY:
+            stats["features"] += sum(len(f) for f in feats)
+            for method in (0, 1, 2):
+                stats["matches"] += len(oracle.matching(po, dims, method, *feats))
+        elif ok:
+            stats["features"] += sum(len(f) for f in feats)
+            for flow in (True, False):
+                if not np.array_equal(pkg.match_all(p, dims, feats[2], feats[0], flow=flow),
+                                      oracle.match_all(po, dims, feats[2], feats[0], flow=flow)):
+                    ok = False
+                    print("FAIL match_all flow=%d:" % flow, tag, flush=True)
+            for method in (0, 1, 2):
+                got = pkg.match(p, dims, method, *feats)
+                want = oracle.matching(po, dims, method, *feats)
+                stats["matches"] += len(want)
+                if got.tobytes() != want.tobytes():
+                    ok = False
+                    print(f"FAIL matching method {method}:", tag, len(got), len(want), flush=True)
+        fails += 0 if ok else 1
+    except Exception as e:  # an error code from the library is a finding too
+        fails += 1
+        print("EXC", type(e).__name__, e, tag, flush=True)
+    if trial % 25 == 0:
+        print(f"[{trial} trials, {fails} failing, {stats['features']} features, {stats['matches']} matches checked]", flush=True)
+print(f"done: {trial} trials, {fails} failing, {stats['features']} features and {stats['matches']} matches compared bit for bit")
+sys.exit(1 if fails else 0)
