@@ -107,7 +107,10 @@ int32_t vh_set_intrinsics(vh_matcher *m, double f, double cu, double cv, double 
 /* Matcher::pushBack(I1,I2,dims,replace) (src/matcher.h:116, src/matcher.cpp:51-91)
  * with the stock computeFeatures behind it (src/matcher.cpp:585-672).
  * I1/I2: host images, row-major u8, stride dims[2] >= dims[0]; I2 may be NULL
- * (mono/flow).  The images are borrowed for the duration of the call. */
+ * (mono/flow).  The images are borrowed for the duration of the call.
+ * A call whose dims differ from the previous one's starts a new sequence: the
+ * ring buffer is emptied (the reference keeps the old pair and would match
+ * across image sizes, src/matcher.cpp:64-84; no caller does that). */
 int32_t vh_push_back(vh_matcher *m, const uint8_t *I1, const uint8_t *I2,
                      const int32_t dims[3], int32_t replace);
 /* Same, images already resident in device memory (e.g. a torch tensor's

@@ -475,3 +475,24 @@ def test_page_locked_host_images_and_staging_slots(pkg, ob, oracle, gpu):
             assert len(want) > 50
             assert ga.getMatches(s).tobytes() == want.tobytes() and gb.getMatches(s).tobytes() == want.tobytes()
     ga.close(); gb.close()
+
+
+@pytest.mark.gpu
+def test_dims_change_starts_a_new_sequence(pkg, ob, oracle, gpu):
+    """A pushBack with different dims re-allocates and empties the ring buffer
+    (include/viso_hip.h); the handle then behaves like a fresh one at the new size."""
+    po = ob.Params.default()
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
+    for (W, H, seed) in ((320, 160, 5), (402, 131, 6), (320, 160, 7)):
+        dims = [W, H, pkg.synth.bytes_per_line(W)]
+        seq = pkg.synth.stereo_sequence(W, H, 2, disparity=6, blur=4, seed=seed)
+        F = [[oracle.compute_features(po, im, dims)[1] for im in pair] for pair in seq]
+        m.pushBack(seq[0][0], seq[0][1], dims, False)
+        m.matchFeatures(pkg.METHOD_QUAD)
+        assert len(m.getMatches()) == 0  # nothing carried over from the previous size
+        assert np.array_equal(m.getFeatures(pkg.SET_1C), F[0][0])
+        m.pushBack(seq[1][0], seq[1][1], dims, False)
+        m.matchFeatures(pkg.METHOD_QUAD)
+        want = oracle.matching(po, dims, 2, F[0][0], F[0][1], F[1][0], F[1][1])
+        assert len(want) > 50 and m.getMatches().tobytes() == want.tobytes()
+    m.close()

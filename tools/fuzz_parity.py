@@ -5,7 +5,12 @@ parameters, for a time budget.  A longer, wider version of
 tests/test_gpu_parity.py::test_random_configs_vs_oracle; prints one line per
 failure with everything needed to reproduce it, and a summary.
 
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tools/fuzz_parity.py [seconds] [seed] [stateless|stateful]
+
+"stateful" drives Matcher / StreamGroup handles instead of the stateless entry
+points: random pushBack(replace) / matchFeatures(method) / removeOutliers /
+bucketFeatures sequences against an emulation of the reference's ring buffer
+(src/matcher.cpp:64-79) on top of the oracle.
 """
 import os
 import sys
@@ -41,6 +46,84 @@ def texture(rng, W, H, dx, dy, spec):
     img[:, W:] = 0
     return np.ascontiguousarray(img)
 
+
+def stateful(budget, seed0):
+    t_end = time.time() + budget
+    trial = fails = checked = 0
+    empty = np.zeros((0, 12), np.int32)
+    while time.time() < t_end:
+        rng = np.random.default_rng(seed0 * 7919 + trial)
+        trial += 1
+        W, H = int(rng.integers(100, 520)), int(rng.integers(80, 260))
+        over = {"nms_n": int(rng.integers(1, 5)), "nms_tau": int(rng.integers(10, 90)),
+                "match_binsize": int(rng.integers(20, 90)), "match_radius": int(rng.integers(20, 260)),
+                "match_disp_tolerance": int(rng.integers(1, 4)), "half_resolution": int(rng.random() < 0.2)}
+        p, po = pkg.Params.default(**over), ob.Params.default(**over)
+        dims = [W, H, synth.bytes_per_line(W)]
+        S = int(rng.integers(1, 4))
+        T = int(rng.integers(3, 7))
+        spec = [(int(rng.integers(0, 3)), int(rng.integers(1, 7)), int(rng.integers(1, 4)), int(rng.integers(1, 100000)), 2.0) for _ in range(S)]
+        tag = f"stateful trial {trial} seed0 {seed0} W {W} H {H} S {S} T {T} {over}"
+        try:
+            g = pkg.StreamGroup(S, p)
+            m = pkg.Matcher(p, outlier_removal=False)
+            prev = [None] * S
+            cur = [None] * S
+            ok = True
+            for t in range(T):
+                replace = bool(t > 0 and rng.random() < 0.25)
+                mono = bool(rng.random() < 0.2)
+                L = [texture(rng, W, H, 3 * t, t, spec[s]) for s in range(S)]
+                R = [texture(rng, W, H, 3 * t + 7, t, spec[s]) for s in range(S)]
+                g.pushBack(np.stack(L), None if mono else np.stack(R), dims, replace)
+                m.pushBack(L[0], None if mono else R[0], dims, replace)
+                for s in range(S):
+                    new = [oracle.compute_features(po, L[s], dims)[1], empty if mono else oracle.compute_features(po, R[s], dims)[1]]
+                    if not replace:
+                        prev[s] = cur[s]
+                    cur[s] = new
+                method = 0 if mono or (prev[0] is not None and len(prev[0][1]) == 0) else int(rng.integers(0, 3))
+                g.matchFeatures(method)
+                m.matchFeatures(method)
+                post = int(rng.integers(0, 3))  # 0 nothing, 1 removeOutliers, 2 removeOutliers + bucketFeatures
+                if post:
+                    g.removeOutliers(2); m.removeOutliers()
+                if post == 2:
+                    m.bucketFeatures(3, 40.0, 30.0)
+                for s in range(S):
+                    pv = prev[s] if prev[s] is not None else [empty, empty]
+                    want = oracle.matching(po, dims, method, pv[0], pv[1], cur[s][0], cur[s][1])
+                    if post and method != 1:
+                        want = oracle.remove_outliers(want)[0]
+                    got = g.getMatches(s)
+                    checked += len(want)
+                    if got.tobytes() != want.tobytes():
+                        ok = False
+                        print(f"FAIL group stream {s} step {t} method {method} post {post}:", tag, len(got), len(want), flush=True)
+                    if s == 0:
+                        if post == 2:
+                            want = oracle.bucket_features(want, 3, 40.0, 30.0)
+                        if m.getMatches().tobytes() != want.tobytes():
+                            ok = False
+                            print(f"FAIL matcher step {t} method {method} post {post}:", tag, flush=True)
+                    for which in range(4):
+                        ref = (pv if which < 2 else cur[s])[which & 1]
+                        if not np.array_equal(g.getFeatures(s, which), ref):
+                            ok = False
+                            print(f"FAIL features stream {s} step {t} which {which}:", tag, flush=True)
+            g.close(); m.close()
+            fails += 0 if ok else 1
+        except Exception as e:
+            fails += 1
+            print("EXC", type(e).__name__, e, tag, flush=True)
+        if trial % 10 == 0:
+            print(f"[{trial} stateful trials, {fails} failing, {checked} matches checked]", flush=True)
+    print(f"done: {trial} stateful trials, {fails} failing, {checked} matches compared bit for bit")
+    return fails
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "stateful":
+    sys.exit(1 if stateful(budget, seed0) else 0)
 
 t_end = time.time() + budget
 trial = 0
