@@ -92,6 +92,19 @@ def cpu_baseline(ob, frames, dims, budget_s: float, over=None):
     return pairs / dt, pairs, dt, results
 
 
+def in_window_pairs(q, c, radius: int) -> int:
+    """(query, candidate) pairs findMatch must evaluate for a flow pass: same
+    class, |du| <= radius, |dv| <= radius (src/matcher.cpp:237-249)."""
+    total = 0
+    for cls in range(4):
+        a, b = q[q[:, 3] == cls], c[c[:, 3] == cls]
+        if len(a) and len(b):
+            du = np.abs(a[:, None, 0] - b[None, :, 0]) <= radius
+            dv = np.abs(a[:, None, 1] - b[None, :, 1]) <= radius
+            total += int(np.count_nonzero(du & dv))
+    return total
+
+
 def stream_assignment(rank: int, n_streams: int):
     """Global stream ids owned by `rank` and their (seed, phase): streams are
     independent camera sequences, sharded rank-major with no overlap."""
@@ -226,6 +239,7 @@ def main():
         if n:
             prof[name] = {"ms_total": ms, "launches": n, "us_per_launch": 1e3 * ms / n}
     nf, nm = grp.getCounts()
+    wl_radius = pkg.Params.default(**wl["params"]).match_radius
     last = (k - 1) % T
     got0 = grp.getMatches(0)
 
@@ -250,9 +264,23 @@ def main():
                         traffic = tr.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # Context for the HBM figure: the flow search's compulsory v_sad_u8 work against the
+            # rate tools/ubench_valu.hip measured for that instruction (profiles/r01_ubench_valu.txt:
+            # 4.86 SIMD-cycles at the nominal 2.4 GHz, 1024 SIMDs) -- 8 SADs per in-window pair
+            valu = None
+            if dom == "match_flow" and nfm.mean() < 20000:  # (the pair count below is O(N^2) host work)
+                pairs_ = []
+                for s_ in range(min(S, 3)):
+                    f = [grp.getFeatures(s_, w_) for w_ in range(4)]
+                    pairs_.append(in_window_pairs(f[1], f[3], wl_radius) + in_window_pairs(f[2], f[0], wl_radius))
+                sad_wave_instr = float(np.mean(pairs_)) * 8 / 64 * S
+                peak = 1024 * 2.4e9 / 4.86
+                valu = {"unit": "v_sad_u8 wave-instructions/s", "achieved": sad_wave_instr / sec, "peak_measured": peak,
+                        "frac": sad_wave_instr / sec / peak, "in_window_pairs_per_stereo_pair": float(np.mean(pairs_))}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "algorithmic_bytes_per_launch": S * B_pair, "us_per_launch": prof[dom]["us_per_launch"],
+                        "valu_sad": valu,
                         "note": "integer SAD search: v_sad_u8 issue-bound, not HBM-bound (DESIGN.md)"}
         out = {
             "metric": METRIC if args.workload == "kitti" else f"stereo frame-pairs/sec (detect+match), {W}x{H}; matches bit-exact",
