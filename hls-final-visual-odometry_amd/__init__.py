@@ -23,7 +23,7 @@ import numpy as np
 from . import synth  # noqa: F401  (synthetic KITTI-shaped frames)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libviso_hip.so")
+LIB_PATH = os.environ.get("VISO_HIP_LIB") or os.path.join(HERE, "libviso_hip.so")  # override: experiment builds
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 

@@ -113,7 +113,7 @@ __device__ __forceinline__ int32_t scan_exclusive(int32_t n, int32_t *sWave, Loa
 }
 
 // One workgroup per set: exclusive scan of the histogram into bin_start, and
-// the list of query tiles (<= 64 consecutive bin-ordered features of one
+// the list of query tiles (<= VH_TILE_Q consecutive bin-ordered features of one
 // (class, u-bin) column) the match kernel works through.
 __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t set0) {
   __shared__ int32_t sWave[VH_SCAN_T / 64];
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t s
   if (tid == 0) bs[s.nbins] = nfeat;
   __syncthreads();  // bin_start is read back below by other lanes
 
-  // query tiles: <= 64 consecutive bin-ordered queries of one tile group.  A
+  // query tiles: <= VH_TILE_Q consecutive bin-ordered queries of one tile group.  A
   // group is one (class, u-bin) column, or -- when the v search window covers
   // the whole image anyway (2*radius >= H), so that mixing columns cannot widen
   // the v range a wave has to walk -- a whole class, which fills the lanes of
@@ -135,12 +135,12 @@ __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t s
   // one group per lane: the per-group tile writes below then spread over the lanes
   const int32_t ntile = scan_exclusive<1>(
       ngroup, sWave,
-      [&](int32_t grp) { return (bs[(grp + 1) * s.tile_span] - bs[grp * s.tile_span] + 63) >> 6; },
+      [&](int32_t grp) { return (bs[(grp + 1) * s.tile_span] - bs[grp * s.tile_span] + VH_TILE_Q - 1) / VH_TILE_Q; },
       [&](int32_t grp, int32_t t0, int32_t nt) {
         const int32_t q0 = bs[grp * s.tile_span], q1 = bs[(grp + 1) * s.tile_span];
         const int32_t cls = (grp * s.tile_span) / (s.ubn * s.vbn);
         for (int32_t k = 0; k < nt; k++, t0++)
-          if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + 64 * k, min(q1, q0 + 64 * k + 64), cls, 0);
+          if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + VH_TILE_Q * k, min(q1, q0 + VH_TILE_Q * k + VH_TILE_Q), cls, 0);
       });
   if (tid == 0) s.tile_cnt[set] = min(ntile, s.max_tiles);
 

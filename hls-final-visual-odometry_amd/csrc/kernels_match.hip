@@ -12,9 +12,8 @@
 //    bin-ordered queries (of one class; of one (class, u-bin) column when the v
 //    window does not span the image).  The candidate stream is then wave-uniform:
 //    all 64 lanes walk the same bin range, candidates are staged 64 at a time in
-//    a wave-private LDS chunk and broadcast-read (VH_MATCH_LDS=0: scalar loads
-//    instead), and the SAD is 8 v_sad_u8 per lane with no cross-lane reduction at
-//    all.  Positions in bin order ARE the reference's visiting order, so its
+//    a wave-private LDS chunk and broadcast-read, and the SAD is 8 v_sad_u8 per
+//    lane and query with no cross-lane reduction at all.  Positions in bin order ARE the reference's visiting order, so its
 //    first-minimum tie-break (strict `<`, src/matcher.cpp:264) is the minimum of
 //    the key (SAD << 19 | position), whatever order candidates arrive in.
 //  * Each lane applies the reference's accept test on its own window
@@ -28,10 +27,6 @@
 #include <type_traits>
 #ifndef VH_FLOW_LDS_PAD_DEFAULT
 #define VH_FLOW_LDS_PAD_DEFAULT 18000
-#endif
-
-#ifndef VH_MATCH_LDS
-#define VH_MATCH_LDS 1
 #endif
 
 namespace {
@@ -55,23 +50,21 @@ __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) {
   return __builtin_amdgcn_sad_u8(a, b, acc);  // v_sad_u8: 4 byte-wise |a-b| summed into acc
 }
 
-__global__ void __launch_bounds__(256)
-match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
-#if VH_MATCH_LDS
-  __shared__ uint4 sDesc[4 * 128];
-  __shared__ uint32_t sUv[4 * 64];
-#endif
-  const int32_t pass = blockIdx.y, stream = blockIdx.z;
+// One tile of the flow search: Q queries per lane (Q*64 consecutive bin-ordered
+// queries per wave); every candidate record is read from LDS once per wave and
+// used for Q queries.  At Q = 1 the broadcast reads (2.25 ds_read_b128 per
+// candidate and wave, 4 LDS cycles each, four SIMDs sharing one LDS array) keep
+// the LDS ~85 % busy beside the 8 v_sad_u8 per candidate; Q = 2 halves that --
+// and was measured 15 % SLOWER on MI355X (flow search alone, S = 128: 1180 vs
+// 1028 us): the kernel is bound by VALU issue, not by the LDS, and a 128-query
+// tile spans more bin columns, so that its lanes evaluate ~10 % more candidates
+// outside their own windows and fewer columns take the cheap accept tests.
+// VH_FLOW_Q (vh_dev.h) therefore stays 1.
+template <int Q>
+__device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream,
+                                          int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c,
+                                          uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
   const int32_t lane = threadIdx.x & 63;
-  const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
-  const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
-  const int32_t ntile = s.tile_cnt[qset];
-  for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); tile < ntile;
-       tile += gridDim.x * 4) {
-  const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
-  const int32_t q0 = __builtin_amdgcn_readfirstlane(t.x), q1 = __builtin_amdgcn_readfirstlane(t.y);
-  const int32_t c = __builtin_amdgcn_readfirstlane(t.z);
-
   const uint32_t *__restrict__ quv = s.s_uv + (int64_t)qset * s.cap;
   const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
   const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
@@ -79,86 +72,89 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
   const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
   const int32_t *__restrict__ cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
-
-  const int32_t q = q0 + lane;
-  const bool valid = q < q1;
-  const int32_t ql = valid ? q : q0;
-  const uint32_t uv1 = quv[ql];
-  const uint4 a0 = qdesc[2 * (int64_t)ql], a1 = qdesc[2 * (int64_t)ql + 1];
-  const int32_t u1 = uv1 & 0xFFFF, v1 = uv1 >> 16;
   const int32_t rv = a.pass[pass].flow ? a.radius : a.disp_tol;
-  // search window (matcher.cpp:231-234; stereo: v narrowed to +-disp_tolerance)
-  const int32_t u_lo = u1 - a.radius, u_hi = u1 + a.radius, v_lo = v1 - rv, v_hi = v1 + rv;
-  // bins of interest (matcher.cpp:237-240); for x<0 the clamp to 0 makes the
-  // truncating division equivalent to the reference's floor
-  int32_t ub_lo = min(max(u_lo, 0) / s.binsize, s.ubn - 1), ub_hi = min(max(u_hi, 0) / s.binsize, s.ubn - 1);
-  int32_t vb_lo = min(max(v_lo, 0) / s.binsize, s.vbn - 1), vb_hi = min(max(v_hi, 0) / s.binsize, s.vbn - 1);
-  if (!valid) { ub_lo = 0x7FFFFFFF; vb_lo = 0x7FFFFFFF; ub_hi = -1; vb_hi = -1; }
+
+  bool valid[Q];
+  uint4 a0[Q], a1[Q];
+  int32_t v_lo[Q];
+  us2 lo2[Q];
+  uint32_t best_key[Q];
+  int32_t ub_lo = 0x7FFFFFFF, vb_lo = 0x7FFFFFFF, ub_hi = -1, vb_hi = -1;
+  int32_t ulo_max = -0x40000000, uhi_min = 0x40000000, vlo_max = -0x40000000, vhi_min = 0x40000000;
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    const int32_t q = q0 + 64 * qi + lane;
+    valid[qi] = q < q1;
+    const int32_t ql = valid[qi] ? q : q0;
+    const uint32_t uv1 = quv[ql];
+    a0[qi] = qdesc[2 * (int64_t)ql]; a1[qi] = qdesc[2 * (int64_t)ql + 1];
+    const int32_t u1 = uv1 & 0xFFFF, v1 = uv1 >> 16;
+    // search window (matcher.cpp:231-234; stereo: v narrowed to +-disp_tolerance)
+    const int32_t u_lo = u1 - a.radius, u_hi = u1 + a.radius, v_hi = v1 + rv;
+    v_lo[qi] = v1 - rv;
+    // Accept test of matcher.cpp:249 in packed 16-bit arithmetic: with
+    // t = (u2,v2) - (u_lo,v_lo) (mod 2^16 per half), the candidate is inside the
+    // window iff t.u <= 2*radius and t.v <= 2*rv, i.e. iff min(t, span) == t.
+    // Exact because coordinates are < 2^14 and radii <= 2^14 (|u2-u1|+r < 2^15).
+    lo2[qi] = us2{(unsigned short)u_lo, (unsigned short)v_lo[qi]};
+    best_key[qi] = 0xFFFFFFFFu;
+    if (valid[qi]) {
+      // bins of interest (matcher.cpp:237-240); for x<0 the clamp to 0 makes the
+      // truncating division equivalent to the reference's floor
+      ub_lo = min(ub_lo, min(max(u_lo, 0) / s.binsize, s.ubn - 1));
+      ub_hi = max(ub_hi, min(max(u_hi, 0) / s.binsize, s.ubn - 1));
+      vb_lo = min(vb_lo, min(max(v_lo[qi], 0) / s.binsize, s.vbn - 1));
+      vb_hi = max(vb_hi, min(max(v_hi, 0) / s.binsize, s.vbn - 1));
+      ulo_max = max(ulo_max, u_lo); uhi_min = min(uhi_min, u_hi);
+      vlo_max = max(vlo_max, v_lo[qi]); vhi_min = min(vhi_min, v_hi);
+    }
+  }
   const int32_t UB0 = __builtin_amdgcn_readfirstlane(wave_min(ub_lo));
   const int32_t UB1 = __builtin_amdgcn_readfirstlane(wave_max(ub_hi));
   const int32_t VB0 = __builtin_amdgcn_readfirstlane(wave_min(vb_lo));
   const int32_t VB1 = __builtin_amdgcn_readfirstlane(wave_max(vb_hi));
-
-  // Accept test of matcher.cpp:249 in packed 16-bit arithmetic: with
-  // t = (u2,v2) - (u_lo,v_lo) (mod 2^16 per half), the candidate is inside the
-  // window iff t.u <= 2*radius and t.v <= 2*rv, i.e. iff min(t, span) == t.
-  // Exact because coordinates are < 2^14 and radii <= 2^14 (|u2-u1|+r < 2^15).
-  const us2 lo2 = {(unsigned short)u_lo, (unsigned short)v_lo};
   const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * rv)};
+  // columns whose pixel range [ub*bs, ub*bs+bs-1] is inside EVERY query's u window
+  const int32_t ULO_MAX = __builtin_amdgcn_readfirstlane(wave_max(ulo_max));
+  const int32_t UHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(uhi_min));
+  // v-bins [VA0, VA1] whose pixel rows lie inside EVERY query's v window: in an
+  // interior column their candidates need no accept test at all
+  const int32_t VLO_MAX = __builtin_amdgcn_readfirstlane(wave_max(vlo_max));
+  const int32_t VHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(vhi_min));
+  const int32_t VA0 = max(VB0, (max(VLO_MAX, 0) + s.binsize - 1) / s.binsize);
+  const int32_t VA1 = min(VB1, (VHI_MIN + 1) / s.binsize - 1);
+
   // best = min over accepted candidates of (SAD << 19 | position): positions in
   // bin order are the reference's visiting order, so this key reproduces its
   // strict-< first-minimum rule (matcher.cpp:264).  SAD <= 8160 < 2^13.
-  uint32_t best_key = 0xFFFFFFFFu;
-  // UTEST=false: the candidate's whole u-bin column lies inside every lane's u
-  // window (wave-uniform fact established per column), so only v is tested.
   // TEST: 2 = full (u,v) window test, 1 = v only, 0 = none (see the column loop)
-  auto make_key = [&](auto test, uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
+  auto make_key = [&](auto test, int32_t qi, uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
     constexpr int TEST = decltype(test)::value;
     bool out = false;
     if (TEST == 2) {
-      const us2 t = as_us2(uv2) - lo2;
+      const us2 t = as_us2(uv2) - lo2[qi];
       const us2 m = __builtin_elementwise_min(t, span2);
       out = as_u32(t) != as_u32(m);
     } else if (TEST == 1) {
-      out = (uint32_t)((int32_t)(uv2 >> 16) - v_lo) > (uint32_t)(2 * rv);
+      out = (uint32_t)((int32_t)(uv2 >> 16) - v_lo[qi]) > (uint32_t)(2 * rv);
     }
-    uint32_t sad = sad4(a0.x, b0.x, 0);
-    sad = sad4(a0.y, b0.y, sad);
-    sad = sad4(a0.z, b0.z, sad);
-    sad = sad4(a0.w, b0.w, sad);
-    sad = sad4(a1.x, b1.x, sad);
-    sad = sad4(a1.y, b1.y, sad);
-    sad = sad4(a1.z, b1.z, sad);
-    sad = sad4(a1.w, b1.w, sad);
+    uint32_t sad = sad4(a0[qi].x, b0.x, 0);
+    sad = sad4(a0[qi].y, b0.y, sad);
+    sad = sad4(a0[qi].z, b0.z, sad);
+    sad = sad4(a0[qi].w, b0.w, sad);
+    sad = sad4(a1[qi].x, b1.x, sad);
+    sad = sad4(a1[qi].y, b1.y, sad);
+    sad = sad4(a1[qi].z, b1.z, sad);
+    sad = sad4(a1[qi].w, b1.w, sad);
     const uint32_t key = (sad << 19) | (uint32_t)p;
     return (TEST != 0 && out) ? 0xFFFFFFFFu : key;
   };
-  auto consider = [&](uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) {
-    best_key = min(best_key, make_key(std::integral_constant<int, 2>{}, uv2, b0, b1, p));
-  };
-  // two candidates per update: min(best, kA, kB) is one v_min3_u32
-  auto consider2 = [&](auto test, uint32_t uvA, const uint4 &a0_, const uint4 &a1_, uint32_t uvB, const uint4 &b0_, const uint4 &b1_, int32_t p) {
-    const uint32_t kA = make_key(test, uvA, a0_, a1_, p), kB = make_key(test, uvB, b0_, b1_, p + 1);
-    best_key = min(min(kA, kB), best_key);
-  };
-  // columns whose pixel range [ub*bs, ub*bs+bs-1] is inside EVERY lane's u window
-  const int32_t ULO_MAX = __builtin_amdgcn_readfirstlane(wave_max(valid ? u_lo : -0x40000000));
-  const int32_t UHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(valid ? u_hi : 0x40000000));
-  // v-bins [VA0, VA1] whose pixel rows lie inside EVERY lane's v window: in an
-  // interior column their candidates need no accept test at all
-  const int32_t VLO_MAX = __builtin_amdgcn_readfirstlane(wave_max(valid ? v_lo : -0x40000000));
-  const int32_t VHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(valid ? v_hi : 0x40000000));
-  const int32_t VA0 = max(VB0, (max(VLO_MAX, 0) + s.binsize - 1) / s.binsize);
-  const int32_t VA1 = min(VB1, (VHI_MIN + 1) / s.binsize - 1);
-#if VH_MATCH_LDS
   // Candidate stream through a wave-private LDS chunk: lane j of the wave fetches
   // candidate p+j (coalesced 36 B per lane), the chunk is then consumed with
   // broadcast reads so that v_sad_u8 runs on VGPR operands (its SGPR-operand form
   // issues ~13 % slower, tools/ubench_valu.hip) and no scalar-load round trips
   // sit in the loop.  The next chunk's global loads are in flight while the
   // current one is consumed.
-  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;   // [64][2] uint4
-  uint32_t *wU = sUv + (threadIdx.x >> 6) * 64;   // [64]
   for (int32_t ub = UB0; ub <= UB1; ub++) {
     const int32_t row = (c * s.ubn + ub) * s.vbn;
     const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
@@ -176,59 +172,68 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
       wU[lane] = gu; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
       int32_t j = 0;
+      // CPI candidates per trip, two per update: min(best, kA, kB) is one v_min3_u32
+      constexpr int CPI = Q == 1 ? 4 : 2;
+      auto run = [&](auto test, int32_t jend) {
+        for (; j + CPI <= jend; j += CPI) {
+#pragma unroll
+          for (int32_t k = 0; k < CPI; k += 2) {
+            const uint32_t uA = wU[j + k], uB = wU[j + k + 1];
+            const uint4 dA0 = wD[2 * (j + k)], dA1 = wD[2 * (j + k) + 1], dB0 = wD[2 * (j + k) + 2], dB1 = wD[2 * (j + k) + 3];
+#pragma unroll
+            for (int32_t qi = 0; qi < Q; qi++) {
+              const uint32_t kA = make_key(test, qi, uA, dA0, dA1, pc + j + k), kB = make_key(test, qi, uB, dB0, dB1, pc + j + k + 1);
+              best_key[qi] = min(min(kA, kB), best_key[qi]);
+            }
+          }
+        }
+        for (; j < jend; j++) {
+          const uint32_t uA = wU[j];
+          const uint4 dA0 = wD[2 * j], dA1 = wD[2 * j + 1];
+#pragma unroll
+          for (int32_t qi = 0; qi < Q; qi++) best_key[qi] = min(best_key[qi], make_key(test, qi, uA, dA0, dA1, pc + j));
+        }
+      };
       if (interior) {
         // [0, ja): v test, [ja, jb): no test, [jb, mcnt): v test
         const int32_t ja = min(max(pa0 - pc, 0), mcnt), jb = min(max(pa1 - pc, ja), mcnt);
-        auto run = [&](auto test, int32_t jend) {
-          for (; j + 4 <= jend; j += 4) {
-#pragma unroll
-            for (int32_t k = 0; k < 4; k += 2)
-              consider2(test, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
-          }
-          for (; j < jend; j++) best_key = min(best_key, make_key(test, wU[j], wD[2 * j], wD[2 * j + 1], pc + j));
-        };
         run(std::integral_constant<int, 1>{}, ja);
         run(std::integral_constant<int, 0>{}, jb);
         run(std::integral_constant<int, 1>{}, mcnt);
       } else {
-        for (; j + 4 <= mcnt; j += 4) {
-#pragma unroll
-          for (int32_t k = 0; k < 4; k += 2)
-            consider2(std::integral_constant<int, 2>{}, wU[j + k], wD[2 * (j + k)], wD[2 * (j + k) + 1], wU[j + k + 1], wD[2 * (j + k) + 2], wD[2 * (j + k) + 3], pc + j + k);
-        }
+        run(std::integral_constant<int, 2>{}, mcnt);
       }
-      for (; j < mcnt; j++) consider(wU[j], wD[2 * j], wD[2 * j + 1], pc + j);
     }
   }
-#else
-  for (int32_t ub = UB0; ub <= UB1; ub++) {
-    const int32_t row = (c * s.ubn + ub) * s.vbn;
-    const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
-    const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + VB1 + 1]);
-    int32_t p = p0;
-    // 4 candidates per trip: the scalar record loads are issued back to back so
-    // that one scalar-cache round trip is paid per 4 candidates, not per candidate
-    for (; p + 4 <= p1; p += 4) {
-      const uint32_t w0 = cuv[p], w1 = cuv[p + 1], w2 = cuv[p + 2], w3 = cuv[p + 3];
-      const uint4 c00 = cdesc[2 * (int64_t)p + 0], c01 = cdesc[2 * (int64_t)p + 1];
-      const uint4 c10 = cdesc[2 * (int64_t)p + 2], c11 = cdesc[2 * (int64_t)p + 3];
-      const uint4 c20 = cdesc[2 * (int64_t)p + 4], c21 = cdesc[2 * (int64_t)p + 5];
-      const uint4 c30 = cdesc[2 * (int64_t)p + 6], c31 = cdesc[2 * (int64_t)p + 7];
-      consider(w0, c00, c01, p);
-      consider(w1, c10, c11, p + 1);
-      consider(w2, c20, c21, p + 2);
-      consider(w3, c30, c31, p + 3);
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    if (valid[qi]) {
+      // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
+      const int32_t r = (best_key[qi] == 0xFFFFFFFFu) ? 0 : cidx[best_key[qi] & 0x7FFFFu];
+      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q0 + 64 * qi + lane]] = r;
     }
-    for (; p < p1; p++) consider(cuv[p], cdesc[2 * (int64_t)p], cdesc[2 * (int64_t)p + 1], p);
   }
-#endif
-  const int32_t best_pos = (best_key == 0xFFFFFFFFu) ? -1 : (int32_t)(best_key & 0x7FFFFu);
-  if (valid) {
-    // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-    const int32_t r = (best_pos >= 0) ? cidx[best_pos] : 0;
-    best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q]] = r;
+}
+
+__global__ void __launch_bounds__(256)
+match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
+  __shared__ uint4 sDesc[4 * 128];
+  __shared__ uint32_t sUv[4 * 64];
+  const int32_t pass = blockIdx.y, stream = blockIdx.z;
+  const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
+  const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
+  const int32_t ntile = s.tile_cnt[qset];
+  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;   // [64][2] uint4
+  uint32_t *wU = sUv + (threadIdx.x >> 6) * 64;   // [64]
+  for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); tile < ntile;
+       tile += gridDim.x * 4) {
+    const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
+    const int32_t q0 = __builtin_amdgcn_readfirstlane(t.x), q1 = __builtin_amdgcn_readfirstlane(t.y);
+    const int32_t c = __builtin_amdgcn_readfirstlane(t.z);
+    // tiles hold up to VH_TILE_Q = 64 * VH_FLOW_Q queries
+    if (VH_FLOW_Q > 1 && q1 - q0 > 64) flow_tile<VH_FLOW_Q>(s, a, pass, stream, qset, cset, q0, q1, c, wD, wU, best);
+    else flow_tile<1>(s, a, pass, stream, qset, cset, q0, q1, c, wD, wU, best);
   }
-  }  // tile loop
 }
 
 // -------------------------------------------------------------- match (stereo)

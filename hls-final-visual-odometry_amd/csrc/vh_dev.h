@@ -34,6 +34,8 @@
 #define VH_MARGIN 7          // src/matcher.cpp:38
 #define VH_CHUNK 1024        // NMS blocks per emit workgroup
 #define VH_WAVE 64
+#define VH_FLOW_Q 1           // queries per lane in the flow search (kernels_match.hip: 2 was measured slower)
+#define VH_TILE_Q (64 * VH_FLOW_Q)  // queries per flow-search tile
 #define VH_NO_CODE 0xFFFFu
 
 struct VhGeom {
