@@ -289,7 +289,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["label"],
                        "streams_per_gpu": S, "frames_in_hbm": T, "features_per_image": float(nfm.mean()),
-                       "matches_per_pair": float(nm.mean()), "parallelism": f"{world}x independent stream groups"},
+                       "matches_per_pair": float(nm.mean()), "parallelism": f"{world}x independent stream groups",
+                       "device_mib_per_stream": round(grp.deviceBytes() / S / 2**20, 2)},
             "roofline": roofline,
             "kernels_us_per_launch": {n_: round(v["us_per_launch"], 2) for n_, v in prof.items()},
         }

@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "vh_create", "vh_create_ex", "vh_destroy", "vh_set_intrinsics", "vh_push_back", "vh_push_back_device",
     "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
     "vh_set_stream", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
-    "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_push_back_device",
+    "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
     "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
@@ -131,6 +131,8 @@ def _lib():
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = None if name.endswith("destroy") else i32
+        lib.vh_group_device_bytes.argtypes = [vp]
+        lib.vh_group_device_bytes.restype = i64
         _LIB = lib
     return _LIB
 
@@ -304,6 +306,10 @@ class StreamGroup:
 
     def matchFeatures(self, method: int):
         _check(_lib().vh_group_match_features(self._h, int(method)), "vh_group_match_features")
+
+    def deviceBytes(self) -> int:
+        """Device memory held by the group (after the first pushBack)."""
+        return int(_lib().vh_group_device_bytes(self._h))
 
     def removeOutliers(self, host_threads: int = 0):
         """Matcher.removeOutliers for every stream, on `host_threads` host workers (0: all)."""

@@ -91,6 +91,7 @@ struct Group {
   void *d_matches = nullptr;
   int32_t *d_match_count = nullptr;
   std::vector<void *> allocs;
+  int64_t device_bytes = 0;
 
   int32_t last_method = -1;
   // streams whose current matches were post-processed on the host
@@ -124,6 +125,7 @@ struct Group {
   void release() {
     for (void *q : allocs) (void)hipFree(q);
     allocs.clear();
+    device_bytes = 0;
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0;
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
@@ -137,6 +139,7 @@ struct Group {
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     VH_HIP(hipMalloc(&q, bytes));
     allocs.push_back(q);
+    device_bytes += (int64_t)bytes;
     if (zero) VH_HIP(hipMemsetAsync(q, 0, bytes, stream));
     *out = (T *)q;
     return VH_OK;
@@ -717,6 +720,7 @@ void vh_group_destroy(vh_group *g) {
   delete gq;
 }
 int32_t vh_group_streams(const vh_group *g) { return g ? ((const Group *)g)->S : VH_ERR_INVALID_ARG; }
+int64_t vh_group_device_bytes(const vh_group *g) { return g ? ((const Group *)g)->device_bytes : (int64_t)VH_ERR_INVALID_ARG; }
 int32_t vh_group_push_back_device(vh_group *g, const void *dI1, const void *dI2, int64_t stride_bytes,
                                   const int32_t dims[3], int32_t replace) {
   Group *gq = (Group *)g; ENTER(gq);

@@ -217,6 +217,9 @@ int32_t vh_group_create(const vh_params *p, int32_t device, int32_t n_streams,
                         int32_t max_features, int32_t max_matches, vh_group **out);
 void vh_group_destroy(vh_group *g);
 int32_t vh_group_streams(const vh_group *g);
+/* Device memory the group currently holds (allocated at the first push_back for
+ * the image size and capacities in use): for sizing S against the HBM of a GPU. */
+int64_t vh_group_device_bytes(const vh_group *g);
 /* Device-resident images: stream s reads dI1 + s*stride_bytes (and dI2 + ...;
  * dI2 may be NULL).  Asynchronous: returns once the work is queued; the images
  * must stay valid until the detection has run (vh_group_synchronize, or the
