@@ -49,6 +49,9 @@ __device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(ui
 __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) {
   return __builtin_amdgcn_sad_u8(a, b, acc);  // v_sad_u8: 4 byte-wise |a-b| summed into acc
 }
+__device__ __forceinline__ uint32_t sad4hi(uint32_t a, uint32_t b, uint32_t acc) {
+  return __builtin_amdgcn_sad_hi_u8(a, b, acc);  // v_sad_hi_u8: the same sum added at bit 16 of acc
+}
 
 // One tile of the flow search: Q queries per lane (Q*64 consecutive bin-ordered
 // queries per wave); every candidate record is read from LDS once per wave and
@@ -60,10 +63,10 @@ __device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) {
 // tile spans more bin columns, so that its lanes evaluate ~10 % more candidates
 // outside their own windows and fewer columns take the cheap accept tests.
 // VH_FLOW_Q (vh_dev.h) therefore stays 1.
-template <int Q>
+template <int Q, bool HI>
 __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream,
                                           int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c,
-                                          uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
+                                          int32_t pbase, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
   const int32_t lane = threadIdx.x & 63;
   const uint32_t *__restrict__ quv = s.s_uv + (int64_t)qset * s.cap;
   const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
@@ -127,6 +130,10 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
   // best = min over accepted candidates of (SAD << 19 | position): positions in
   // bin order are the reference's visiting order, so this key reproduces its
   // strict-< first-minimum rule (matcher.cpp:264).  SAD <= 8160 < 2^13.
+  // HI: when the positions this tile can visit span less than 2^16, the key is
+  // (SAD << 16 | position - pbase) instead and costs nothing to build: the SAD
+  // chain runs on v_sad_hi_u8, which accumulates at bit 16, seeded with the
+  // relative position in the low half.
   // TEST: 2 = full (u,v) window test, 1 = v only, 0 = none (see the column loop)
   auto make_key = [&](auto test, int32_t qi, uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
     constexpr int TEST = decltype(test)::value;
@@ -138,15 +145,27 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
     } else if (TEST == 1) {
       out = (uint32_t)((int32_t)(uv2 >> 16) - v_lo[qi]) > (uint32_t)(2 * rv);
     }
-    uint32_t sad = sad4(a0[qi].x, b0.x, 0);
-    sad = sad4(a0[qi].y, b0.y, sad);
-    sad = sad4(a0[qi].z, b0.z, sad);
-    sad = sad4(a0[qi].w, b0.w, sad);
-    sad = sad4(a1[qi].x, b1.x, sad);
-    sad = sad4(a1[qi].y, b1.y, sad);
-    sad = sad4(a1[qi].z, b1.z, sad);
-    sad = sad4(a1[qi].w, b1.w, sad);
-    const uint32_t key = (sad << 19) | (uint32_t)p;
+    uint32_t key;
+    if (HI) {
+      key = sad4hi(a0[qi].x, b0.x, (uint32_t)(p - pbase));
+      key = sad4hi(a0[qi].y, b0.y, key);
+      key = sad4hi(a0[qi].z, b0.z, key);
+      key = sad4hi(a0[qi].w, b0.w, key);
+      key = sad4hi(a1[qi].x, b1.x, key);
+      key = sad4hi(a1[qi].y, b1.y, key);
+      key = sad4hi(a1[qi].z, b1.z, key);
+      key = sad4hi(a1[qi].w, b1.w, key);
+    } else {
+      uint32_t sad = sad4(a0[qi].x, b0.x, 0);
+      sad = sad4(a0[qi].y, b0.y, sad);
+      sad = sad4(a0[qi].z, b0.z, sad);
+      sad = sad4(a0[qi].w, b0.w, sad);
+      sad = sad4(a1[qi].x, b1.x, sad);
+      sad = sad4(a1[qi].y, b1.y, sad);
+      sad = sad4(a1[qi].z, b1.z, sad);
+      sad = sad4(a1[qi].w, b1.w, sad);
+      key = (sad << 19) | (uint32_t)p;
+    }
     return (TEST != 0 && out) ? 0xFFFFFFFFu : key;
   };
   // Candidate stream through a wave-private LDS chunk: lane j of the wave fetches
@@ -209,7 +228,8 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
   for (int32_t qi = 0; qi < Q; qi++) {
     if (valid[qi]) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t r = (best_key[qi] == 0xFFFFFFFFu) ? 0 : cidx[best_key[qi] & 0x7FFFFu];
+      const int32_t bp = HI ? pbase + (int32_t)(best_key[qi] & 0xFFFFu) : (int32_t)(best_key[qi] & 0x7FFFFu);
+      const int32_t r = (best_key[qi] == 0xFFFFFFFFu) ? 0 : cidx[bp];
       best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q0 + 64 * qi + lane]] = r;
     }
   }
@@ -230,9 +250,18 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
     const int32_t q0 = __builtin_amdgcn_readfirstlane(t.x), q1 = __builtin_amdgcn_readfirstlane(t.y);
     const int32_t c = __builtin_amdgcn_readfirstlane(t.z);
+    // candidates of class c occupy the contiguous positions [pbase, pend) of the bin order
+    const int32_t *cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
+    const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
+    const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
     // tiles hold up to VH_TILE_Q = 64 * VH_FLOW_Q queries
-    if (VH_FLOW_Q > 1 && q1 - q0 > 64) flow_tile<VH_FLOW_Q>(s, a, pass, stream, qset, cset, q0, q1, c, wD, wU, best);
-    else flow_tile<1>(s, a, pass, stream, qset, cset, q0, q1, c, wD, wU, best);
+    if (pend - pbase <= 0xFFFF && !a.wide_keys) {
+      if (VH_FLOW_Q > 1 && q1 - q0 > 64) flow_tile<VH_FLOW_Q, true>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
+      else flow_tile<1, true>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
+    } else {
+      if (VH_FLOW_Q > 1 && q1 - q0 > 64) flow_tile<VH_FLOW_Q, false>(s, a, pass, stream, qset, cset, q0, q1, c, 0, wD, wU, best);
+      else flow_tile<1, false>(s, a, pass, stream, qset, cset, q0, q1, c, 0, wD, wU, best);
+    }
   }
 }
 
@@ -559,7 +588,9 @@ void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, dou
   hipLaunchKernelGGL(match_prior_kernel, dim3((s.cap + 127) / 128), dim3(128), 0, st, s, a, u_, v_, best);
 }
 void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
-  const VhMatchArgs fl = filter_passes(a, 1);
+  VhMatchArgs fl = filter_passes(a, 1);
+  static const int wide = [] { const char *e = getenv("VH_FLOW_WIDE_KEYS"); return e ? atoi(e) : 0; }();
+  fl.wide_keys = wide;
   if (!fl.npass) return;
   // One workgroup per 4 tiles of the capacity-sized tile list (the kernel loops,
   // so any grid is correct).  At typical densities ~75 % of these workgroups

@@ -89,6 +89,7 @@ struct VhMatchArgs {
   int32_t pair_cur;  // ring slots: current frame | previous frame << 8
   int32_t S;
   int32_t radius, disp_tol;
+  int32_t wide_keys;  // 1: never use the 16-bit relative position keys of the flow search (VH_FLOW_WIDE_KEYS=1; test hook)
 };
 
 __host__ __device__ inline int32_t vh_set_id(int32_t S, int32_t pair, int32_t stream, int32_t cam) {

@@ -496,3 +496,17 @@ def test_dims_change_starts_a_new_sequence(pkg, ob, oracle, gpu):
         want = oracle.matching(po, dims, 2, F[0][0], F[0][1], F[1][0], F[1][1])
         assert len(want) > 50 and m.getMatches().tobytes() == want.tobytes()
     m.close()
+
+
+@pytest.mark.gpu
+def test_flow_search_wide_key_path(gpu):
+    """The flow search builds (SAD << 16 | relative position) keys on v_sad_hi_u8
+    when a class holds fewer than 2^16 candidates, else (SAD << 19 | position).
+    The second path is forced here (VH_FLOW_WIDE_KEYS=1, read once per process,
+    hence the subprocess) and must pass the same parity cases."""
+    import subprocess, sys
+    env = dict(os.environ, VH_FLOW_WIDE_KEYS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "golden or random_configs or tie_break or ring_buffer"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
