@@ -325,36 +325,62 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const int32_t VHI = min(__builtin_amdgcn_readfirstlane(wave_max(valid ? v1 : -1)) + a.disp_tol, s.H - 1);
     const int32_t r0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VLO]);
     const int32_t r1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VHI + 1]);
+    // key = SAD << 16 | (bin-order position - class base) straight out of a
+    // v_sad_hi_u8 chain when the class holds < 2^16 candidates (see flow_tile),
+    // else SAD << 19 | position
+    const int32_t *cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
+    const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
+    const bool hi = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]) - pbase <= 0xFFFF && !a.wide_keys;
     uint32_t best_key = 0xFFFFFFFFu;
     for (int32_t rc = r0; rc < r1; rc += 64) {
       const int32_t mcnt = min(64, r1 - rc);
       const int32_t rl = min(rc + lane, r1 - 1);
       const int32_t cp = cpos[rl];
-      const uint2 gm = make_uint2(cuv[cp], (uint32_t)cp);
+      const uint2 gm = make_uint2(cuv[cp], (uint32_t)(hi ? cp - pbase : cp));
       const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
       wM[lane] = gm; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
-      for (int32_t j = 0; j < mcnt; j++) {
-        const uint2 cm = wM[j];
-        const uint4 b0 = wD[2 * j], b1 = wD[2 * j + 1];
-        const us2 tt = as_us2(cm.x) - lo2;
-        const us2 mm = __builtin_elementwise_min(tt, span2);
-        const bool out = as_u32(tt) != as_u32(mm);
-        uint32_t sad = sad4(a0.x, b0.x, 0);
-        sad = sad4(a0.y, b0.y, sad);
-        sad = sad4(a0.z, b0.z, sad);
-        sad = sad4(a0.w, b0.w, sad);
-        sad = sad4(a1.x, b1.x, sad);
-        sad = sad4(a1.y, b1.y, sad);
-        sad = sad4(a1.z, b1.z, sad);
-        sad = sad4(a1.w, b1.w, sad);
-        best_key = min(best_key, out ? 0xFFFFFFFFu : ((sad << 19) | cm.y));
+      if (hi) {
+        for (int32_t j = 0; j < mcnt; j++) {
+          const uint2 cm = wM[j];
+          const uint4 b0 = wD[2 * j], b1 = wD[2 * j + 1];
+          const us2 tt = as_us2(cm.x) - lo2;
+          const us2 mm = __builtin_elementwise_min(tt, span2);
+          const bool out = as_u32(tt) != as_u32(mm);
+          uint32_t key = sad4hi(a0.x, b0.x, cm.y);
+          key = sad4hi(a0.y, b0.y, key);
+          key = sad4hi(a0.z, b0.z, key);
+          key = sad4hi(a0.w, b0.w, key);
+          key = sad4hi(a1.x, b1.x, key);
+          key = sad4hi(a1.y, b1.y, key);
+          key = sad4hi(a1.z, b1.z, key);
+          key = sad4hi(a1.w, b1.w, key);
+          best_key = min(best_key, out ? 0xFFFFFFFFu : key);
+        }
+      } else {
+        for (int32_t j = 0; j < mcnt; j++) {
+          const uint2 cm = wM[j];
+          const uint4 b0 = wD[2 * j], b1 = wD[2 * j + 1];
+          const us2 tt = as_us2(cm.x) - lo2;
+          const us2 mm = __builtin_elementwise_min(tt, span2);
+          const bool out = as_u32(tt) != as_u32(mm);
+          uint32_t sad = sad4(a0.x, b0.x, 0);
+          sad = sad4(a0.y, b0.y, sad);
+          sad = sad4(a0.z, b0.z, sad);
+          sad = sad4(a0.w, b0.w, sad);
+          sad = sad4(a1.x, b1.x, sad);
+          sad = sad4(a1.y, b1.y, sad);
+          sad = sad4(a1.z, b1.z, sad);
+          sad = sad4(a1.w, b1.w, sad);
+          best_key = min(best_key, out ? 0xFFFFFFFFu : ((sad << 19) | cm.y));
+        }
       }
     }
     if (valid) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t res = (best_key == 0xFFFFFFFFu) ? 0 : cidx[best_key & 0x7FFFFu];
+      const int32_t bp = hi ? pbase + (int32_t)(best_key & 0xFFFFu) : (int32_t)(best_key & 0x7FFFFu);
+      const int32_t res = (best_key == 0xFFFFFFFFu) ? 0 : cidx[bp];
       best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[qm.y]] = res;
     }
   }
@@ -578,7 +604,9 @@ static VhMatchArgs filter_passes(const VhMatchArgs &a, int32_t flow) {
   return r;
 }
 void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
-  const VhMatchArgs sr = filter_passes(a, 0);
+  VhMatchArgs sr = filter_passes(a, 0);
+  static const int wide = [] { const char *e = getenv("VH_FLOW_WIDE_KEYS"); return e ? atoi(e) : 0; }();
+  sr.wide_keys = wide;
   if (!sr.npass) return;
   dim3 grid(std::min(std::max(s.cap / 1024, 8), 1024), sr.npass, a.S);  // 4 tiles of 64 queries per workgroup per trip
   hipLaunchKernelGGL(match_rows_kernel, grid, dim3(256), 0, st, s, sr, best);
