@@ -341,14 +341,14 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
       wM[lane] = gm; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
-      if (hi) {
-        for (int32_t j = 0; j < mcnt; j++) {
-          const uint2 cm = wM[j];
-          const uint4 b0 = wD[2 * j], b1 = wD[2 * j + 1];
-          const us2 tt = as_us2(cm.x) - lo2;
-          const us2 mm = __builtin_elementwise_min(tt, span2);
-          const bool out = as_u32(tt) != as_u32(mm);
-          uint32_t key = sad4hi(a0.x, b0.x, cm.y);
+      // four candidates per trip (their LDS reads are issued together), then the rest
+      auto key_of = [&](auto hi_, const uint2 cm, const uint4 &b0, const uint4 &b1) -> uint32_t {
+        const us2 tt = as_us2(cm.x) - lo2;
+        const us2 mm = __builtin_elementwise_min(tt, span2);
+        const bool out = as_u32(tt) != as_u32(mm);
+        uint32_t key;
+        if (decltype(hi_)::value) {
+          key = sad4hi(a0.x, b0.x, cm.y);
           key = sad4hi(a0.y, b0.y, key);
           key = sad4hi(a0.z, b0.z, key);
           key = sad4hi(a0.w, b0.w, key);
@@ -356,15 +356,7 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
           key = sad4hi(a1.y, b1.y, key);
           key = sad4hi(a1.z, b1.z, key);
           key = sad4hi(a1.w, b1.w, key);
-          best_key = min(best_key, out ? 0xFFFFFFFFu : key);
-        }
-      } else {
-        for (int32_t j = 0; j < mcnt; j++) {
-          const uint2 cm = wM[j];
-          const uint4 b0 = wD[2 * j], b1 = wD[2 * j + 1];
-          const us2 tt = as_us2(cm.x) - lo2;
-          const us2 mm = __builtin_elementwise_min(tt, span2);
-          const bool out = as_u32(tt) != as_u32(mm);
+        } else {
           uint32_t sad = sad4(a0.x, b0.x, 0);
           sad = sad4(a0.y, b0.y, sad);
           sad = sad4(a0.z, b0.z, sad);
@@ -373,9 +365,25 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
           sad = sad4(a1.y, b1.y, sad);
           sad = sad4(a1.z, b1.z, sad);
           sad = sad4(a1.w, b1.w, sad);
-          best_key = min(best_key, out ? 0xFFFFFFFFu : ((sad << 19) | cm.y));
+          key = (sad << 19) | cm.y;
         }
-      }
+        return out ? 0xFFFFFFFFu : key;
+      };
+      auto consume = [&](auto hi_) {
+        int32_t j = 0;
+        for (; j + 4 <= mcnt; j += 4) {
+          uint2 cm[4];
+          uint4 b0[4], b1[4];
+#pragma unroll
+          for (int32_t k = 0; k < 4; k++) { cm[k] = wM[j + k]; b0[k] = wD[2 * (j + k)]; b1[k] = wD[2 * (j + k) + 1]; }
+          const uint32_t k0 = key_of(hi_, cm[0], b0[0], b1[0]), k1 = key_of(hi_, cm[1], b0[1], b1[1]);
+          const uint32_t k2 = key_of(hi_, cm[2], b0[2], b1[2]), k3 = key_of(hi_, cm[3], b0[3], b1[3]);
+          best_key = min(min(min(k0, k1), min(k2, k3)), best_key);
+        }
+        for (; j < mcnt; j++) best_key = min(best_key, key_of(hi_, wM[j], wD[2 * j], wD[2 * j + 1]));
+      };
+      if (hi) consume(std::true_type{});
+      else consume(std::false_type{});
     }
     if (valid) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
