@@ -26,6 +26,7 @@
 //                 the image (16 lanes per feature, one sample point each): the
 //                 Sobel planes the reference materialises are never written.
 #include "vh_dev.h"
+#include <type_traits>
 
 namespace {
 
@@ -210,29 +211,18 @@ template <int N> struct DetTile {
   static constexpr int ROWS = (FH + NSEG - 1) / NSEG;
 };
 
-typedef short s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s2 as_s2(uint32_t x) { return __builtin_bit_cast(s2, x); }
-
-template <int N, bool IS_MIN> __device__ __forceinline__ int32_t fold_window(const int32_t (&w)[2 * N + 1]) {
-  int32_t r = w[0];
-#pragma unroll
-  for (int32_t k = 1; k + 1 < 2 * N + 1; k += 2) r = IS_MIN ? min(r, min(w[k], w[k + 1])) : max(r, max(w[k], w[k + 1]));
-  return r;  // 2N+1 is odd: pairs (1,2),(3,4),... cover everything after w[0]
-}
 
 template <int N>
 __global__ void __launch_bounds__(256)
 detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__restrict__ chunk_count) {
   using T = DetTile<N>;
   constexpr int N1 = T::N1, WN = 2 * N + 1;
-  constexpr int VH_ROWS = T::FH - 2 * N;                       // rows that can hold a block extremum
-  constexpr int X_BYTES = (T::IH * T::IP > 4 * VH_ROWS * T::FP) ? T::IH * T::IP : 4 * VH_ROWS * T::FP;
+  constexpr int X_BYTES = (T::IH * T::IP > 5120) ? T::IH * T::IP : 5120;
   __shared__ __attribute__((aligned(16))) int16_t sF1[T::FH * T::FP];
   __shared__ __attribute__((aligned(16))) int16_t sF2[T::FH * T::FP];
-  // scratch: first the staged image tile, later the window-min / window-max planes
+  // scratch: first the staged image tile, later the NMS candidate queues and pass flags
   __shared__ __attribute__((aligned(16))) uint8_t sX[X_BYTES];
   uint8_t *sI = sX;
-  int16_t *sVmin = (int16_t *)sX, *sVmax = sVmin + VH_ROWS * T::FP;
 
   const int32_t id = blockIdx.z, tid = threadIdx.x;
   const uint8_t *__restrict__ I = vh_image_ptr(im, id);
@@ -285,56 +275,32 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   //    (matcher.cpp:420-426) is, because the candidate is already the minimum of
   //    its own block, the same as "the candidate equals the minimum of the whole
   //    window".  The window is clipped at W-1-margin / H-1-margin on the high
-  //    side only, which row/column replication reproduces.  So: (a) vertical
-  //    (2n+1)-row min/max of the response plane into LDS, (b) per block: extrema
-  //    (first in scan order, matcher.cpp:393-417), threshold, and a (2n+1)-wide
-  //    horizontal min/max over the vertical one.  Done for f1 then f2 through
-  //    the same scratch planes.
+  //    side only, which row/column replication reproduces.  (a) One lane per
+  //    block finds the four block extrema (first in scan order,
+  //    matcher.cpp:393-417) and applies the threshold (matcher.cpp:427,439,451,
+  //    463); only ~13 % of them pass it on typical images, and those are queued
+  //    in LDS.  (b) The queued candidates are checked one per lane by reading
+  //    their whole window: far fewer instructions than window extrema for every
+  //    pixel, and the queue keeps all lanes of the checking waves busy.
   const int32_t xlim = min(max((g.Wm - 1 - VH_MARGIN) - fx0, 0), T::FW - 1);
   const int32_t ylim = min(max((g.Hm - 1 - VH_MARGIN) - fy0, 0), T::FH - 1);
   const int32_t lby = tid / T::TBX, lbx = tid % T::TBX;
   const int32_t bx = bx0 + lbx, by = by0 + lby;
   const bool have_block = bx < g.nbx && by < g.nby;
   const int32_t fx = N + lbx * N1, fy = N + lby * N1;
-  uint32_t codes[4];
+  // queues: [0] minima, [1] maxima; entry = owner | type << 8 | row << 10 | column << 16
+  uint32_t *sQueue = (uint32_t *)sX;             // [2][512]
+  uint32_t *sPass = sQueue + 1024;               // [256]: one byte per (block, type)
+  __shared__ int32_t sQueueN[2];
+  if (tid < 2) sQueueN[tid] = 0;
+  sPass[tid] = 0;
+  __syncthreads();
+  uint32_t pos[4];
+  {
+    const int32_t lane = tid & 63;
 #pragma unroll
-  for (int32_t plane = 0; plane < 2; plane++) {
-    const int16_t *F = plane ? sF2 : sF1;
-    // (a) vertical window extrema, one column PAIR per lane (packed i16: v_pk_min_i16 /
-    //     v_pk_max_i16 do two columns per instruction), sliding down the rows
-    {
-      constexpr int CP = T::FP / 2;  // column pairs per row
-      constexpr int NSV = (256 / CP) > 0 ? (256 / CP) : 1;
-      constexpr int RSV = (VH_ROWS + NSV - 1) / NSV;
-      const uint32_t *F2 = (const uint32_t *)F;
-      uint32_t *vmin2 = (uint32_t *)sVmin, *vmax2 = (uint32_t *)sVmax;
-      for (int32_t task = tid; task < CP * NSV; task += 256) {
-        const int32_t seg = task / CP, cp = task - seg * CP;
-        const int32_t a = N + seg * RSV;  // first output row of this segment
-        s2 w[WN];
-#pragma unroll
-        for (int32_t k = 0; k < WN - 1; k++) w[k + 1] = as_s2(F2[min(a - N + k, ylim) * CP + cp]);
-#pragma unroll
-        for (int32_t i = 0; i < RSV; i++) {
-          const int32_t r = a + i;
-          if (r < T::FH - N) {
-#pragma unroll
-            for (int32_t k = 0; k < WN - 1; k++) w[k] = w[k + 1];
-            w[WN - 1] = as_s2(F2[min(r + N, ylim) * CP + cp]);
-            s2 mn = w[0], mx = w[0];
-#pragma unroll
-            for (int32_t k = 1; k < WN; k++) { mn = __builtin_elementwise_min(mn, w[k]); mx = __builtin_elementwise_max(mx, w[k]); }
-            vmin2[(r - N) * CP + cp] = __builtin_bit_cast(uint32_t, mn);
-            vmax2[(r - N) * CP + cp] = __builtin_bit_cast(uint32_t, mx);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // (b) one lane per NMS block, branch-free (selects, unconditional reads)
-    uint32_t cmin = VH_NO_CODE, cmax = VH_NO_CODE;
-    {
-      const int16_t *b = F + fy * T::FP + fx;
+    for (int32_t plane = 0; plane < 2; plane++) {
+      const int16_t *b = (plane ? sF2 : sF1) + fy * T::FP + fx;
       int32_t vn = b[0], vx = vn, pn = 0, px = 0;
 #pragma unroll
       for (int32_t j = 0; j < N1; j++) {
@@ -347,23 +313,72 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
           vx = gt ? cur : vx; px = gt ? kk : px;
         }
       }
-      // candidate == extremum of its clipped (2N+1)^2 window?  (vertical part precomputed)
-      const int16_t *vmn = sVmin + (fy + (pn >> 6) - N) * T::FP;
-      const int16_t *vmx = sVmax + (fy + (px >> 6) - N) * T::FP;
-      const int32_t cn = fx + (pn & 63), cx_ = fx + (px & 63);
-      int32_t wn = vmn[min(cn - N, xlim)], wx = vmx[min(cx_ - N, xlim)];
+      pos[2 * plane] = (uint32_t)pn;
+      pos[2 * plane + 1] = (uint32_t)px;
 #pragma unroll
-      for (int32_t k = -N + 1; k <= N; k++) {
-        wn = min(wn, (int32_t)vmn[min(cn + k, xlim)]);
-        wx = max(wx, (int32_t)vmx[min(cx_ + k, xlim)]);
+      for (int32_t mm = 0; mm < 2; mm++) {  // 0: the block minimum, 1: the block maximum
+        const bool cand = have_block && (mm ? vx >= g.tau : vn <= -g.tau);
+        const uint32_t pc = mm ? (uint32_t)px : (uint32_t)pn;
+        const uint64_t bal = __ballot(cand);
+        if (bal) {  // wave-uniform
+          int32_t base = 0;
+          if (lane == 0) base = atomicAdd(&sQueueN[mm], (int32_t)__popcll(bal));
+          base = __builtin_amdgcn_readfirstlane(base);
+          const int32_t rank = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          if (cand)
+            sQueue[mm * 512 + base + rank] =
+                (uint32_t)tid | ((uint32_t)(2 * plane + mm) << 8) | ((uint32_t)(fy + (pc >> 6)) << 10) | ((uint32_t)(fx + (pc & 63)) << 16);
+        }
       }
-      // threshold (matcher.cpp:427,439,451,463) and dominance
-      if (have_block && vn <= -g.tau && wn >= vn) cmin = (uint32_t)pn;
-      if (have_block && vx >= g.tau && wx <= vx) cmax = (uint32_t)px;
     }
-    codes[2 * plane] = cmin;
-    codes[2 * plane + 1] = cmax;
-    if (plane == 0) __syncthreads();  // scratch planes are rewritten for f2
+  }
+  __syncthreads();
+  {
+    // waves 0-1 check the minima, waves 2-3 the maxima.  Tiles that do not touch
+    // the high-side clipping limits (almost all) address the window relative to
+    // its top-left corner, so that every read offset is an immediate.
+    const int32_t mm = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int32_t nq = sQueueN[mm];
+    const bool unclipped = xlim == T::FW - 1 && ylim == T::FH - 1;
+    auto check = [&](auto is_max, auto no_clip) {
+      for (int32_t e = tid & 127; e < nq; e += 128) {
+        const uint32_t q = sQueue[mm * 512 + e];
+        const int32_t owner = q & 255, type = (q >> 8) & 3, cy = (q >> 10) & 63, cx = q >> 16;
+        const int16_t *F = (type & 2) ? sF2 : sF1;
+        int32_t v[WN * WN];
+        if (decltype(no_clip)::value) {
+          const int16_t *w = F + (cy - N) * T::FP + (cx - N);
+#pragma unroll
+          for (int32_t j = 0; j < WN; j++)
+#pragma unroll
+            for (int32_t k = 0; k < WN; k++) v[j * WN + k] = w[j * T::FP + k];
+        } else {
+          int32_t col[WN];
+#pragma unroll
+          for (int32_t k = 0; k < WN; k++) col[k] = min(cx - N + k, xlim);
+#pragma unroll
+          for (int32_t j = 0; j < WN; j++) {
+            const int16_t *row = F + min(cy - N + j, ylim) * T::FP;
+#pragma unroll
+            for (int32_t k = 0; k < WN; k++) v[j * WN + k] = row[col[k]];
+          }
+        }
+        const int32_t centre = v[N * WN + N];
+        int32_t ext = centre;
+#pragma unroll
+        for (int32_t k = 0; k < WN * WN; k++) ext = decltype(is_max)::value ? max(ext, v[k]) : min(ext, v[k]);
+        if (ext == centre) ((uint8_t *)sPass)[owner * 4 + type] = 1;
+      }
+    };
+    if (mm) { if (unclipped) check(std::true_type{}, std::true_type{}); else check(std::true_type{}, std::false_type{}); }
+    else { if (unclipped) check(std::false_type{}, std::true_type{}); else check(std::false_type{}, std::false_type{}); }
+  }
+  __syncthreads();
+  uint32_t codes[4];
+  {
+    const uint32_t ok = sPass[tid];
+#pragma unroll
+    for (int32_t c = 0; c < 4; c++) codes[c] = ((ok >> (8 * c)) & 1) ? pos[c] : VH_NO_CODE;
   }
 
   // 4. 8 bytes per block + the per-chunk survivor counts.  The counts are first
