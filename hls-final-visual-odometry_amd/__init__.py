@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
     "vh_set_stream", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
-    "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_features",
+    "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
 )
@@ -122,6 +122,7 @@ def _lib():
             "vh_group_push_back_device": [vp, vp, vp, i64, vp, i32],
             "vh_group_push_back": [vp, vp, vp, i64, vp, i32],
             "vh_group_match_features": [vp, i32], "vh_group_get_matches": [vp, i32, vp, i32, vp],
+            "vh_group_get_matches_all": [vp, vp, i32, vp],
             "vh_group_get_features": [vp, i32, i32, vp, i32, vp], "vh_group_get_counts": [vp, vp, vp],
             "vh_group_synchronize": [vp], "vh_group_set_stream": [vp, vp],
             "vh_group_profile_enable": [vp, i32], "vh_group_profile_read": [vp, C.c_char_p, vp, vp],
@@ -333,6 +334,18 @@ class StreamGroup:
             _check(_lib().vh_group_get_features(self._h, stream, which, _ptr(out), n.value, C.byref(n)),
                    "vh_group_get_features")
         return out
+
+    def getMatchesAll(self, out: np.ndarray | None = None, cap_per_stream: int | None = None):
+        """-> (records [S, cap_per_stream] P_MATCH_DTYPE, counts [S]); one wait for the whole group.
+        Pass `out` (e.g. from pinned_empty) to reuse a buffer."""
+        if out is None:
+            if cap_per_stream is None:
+                cap_per_stream = int(self.getCounts()[1].max(initial=0))
+            out = np.zeros((self.S, max(cap_per_stream, 1)), P_MATCH_DTYPE)
+        assert out.dtype == P_MATCH_DTYPE and out.ndim == 2 and out.shape[0] == self.S and out.flags.c_contiguous
+        counts = np.zeros(self.S, np.int32)
+        _check(_lib().vh_group_get_matches_all(self._h, _ptr(out), out.shape[1], _ptr(counts)), "vh_group_get_matches_all")
+        return out, counts
 
     def getCounts(self):
         nf = np.zeros((self.S, 4), np.int32)

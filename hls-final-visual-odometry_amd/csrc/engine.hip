@@ -494,6 +494,33 @@ struct Group {
     return VH_OK;
   }
 
+  // All streams' matches in one go: counts first, then one transfer per stream
+  // into out[s * cap_per_stream ...], a single wait at the end.
+  int32_t get_matches_all(vh_p_match *out, int32_t cap_per_stream, int32_t *counts) {
+    if (!out || !counts || cap_per_stream < 0) return VH_ERR_INVALID_ARG;
+    for (int32_t s = 0; s < S; s++) counts[s] = 0;
+    if (!allocated || last_method < 0) return VH_OK;
+    VH_HIP(hipMemcpyAsync(counts, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipStreamSynchronize(post_stream));
+    bool over = false;
+    for (int32_t s = 0; s < S; s++) {
+      if (host_filtered[s]) {
+        counts[s] = (int32_t)host_matches[s].size();
+        const int32_t k = std::min(counts[s], cap_per_stream);
+        if (k) memcpy(out + (size_t)s * cap_per_stream, host_matches[s].data(), sizeof(vh_p_match) * (size_t)k);
+        over = over || counts[s] > cap_per_stream;
+        continue;
+      }
+      const int32_t k = std::min(std::min(counts[s], mcap), cap_per_stream);
+      over = over || counts[s] > cap_per_stream || counts[s] > mcap;
+      if (k > 0)
+        VH_HIP(hipMemcpyAsync(out + (size_t)s * cap_per_stream, (const uint8_t *)d_matches + (size_t)s * mcap * sizeof(vh_p_match),
+                              sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, post_stream));
+    }
+    VH_HIP(hipStreamSynchronize(post_stream));
+    return over ? VH_ERR_CAPACITY : VH_OK;
+  }
+
   // Bring stream s's current matches to the host (no-op if already there).
   int32_t fetch_matches(int32_t s) {
     if (s < 0 || s >= S) return VH_ERR_INVALID_ARG;
@@ -738,6 +765,10 @@ int32_t vh_group_match_features(vh_group *g, int32_t method) {
 int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32_t cap, int32_t *n) {
   Group *gq = (Group *)g; ENTER(gq);
   return gq->get_matches(stream, out, cap, n);
+}
+int32_t vh_group_get_matches_all(vh_group *g, vh_p_match *out, int32_t cap_per_stream, int32_t *counts) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->get_matches_all(out, cap_per_stream, counts);
 }
 int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_t *out12, int32_t cap, int32_t *n) {
   Group *gq = (Group *)g; ENTER(gq);

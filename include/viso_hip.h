@@ -236,6 +236,11 @@ int32_t vh_group_match_features(vh_group *g, int32_t method);
 int32_t vh_group_remove_outliers(vh_group *g, int32_t host_threads);
 int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32_t cap,
                              int32_t *n);
+/* Every stream's matches with one wait: stream s's records go to
+ * out[s * cap_per_stream ...], its true count to counts[s] (VH_ERR_CAPACITY if
+ * any count exceeds cap_per_stream; the records that fit are still written).
+ * `out` in page-locked memory (vh_host_alloc) makes the transfers run at PCIe rate. */
+int32_t vh_group_get_matches_all(vh_group *g, vh_p_match *out, int32_t cap_per_stream, int32_t *counts);
 int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_t *out12,
                               int32_t cap, int32_t *n);
 /* Per-stream counts of the last step without copying records:

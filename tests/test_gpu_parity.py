@@ -510,3 +510,32 @@ def test_flow_search_wide_key_path(gpu):
                         "golden or random_configs or tie_break or ring_buffer"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_group_get_matches_all(pkg, ob, oracle, gpu):
+    """vh_group_get_matches_all == per-stream vh_group_get_matches, also after the
+    host-side outlier vote and into a page-locked buffer."""
+    W, H, S = 320, 160, 4
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, 2, disparity=4 + s, blur=4, seed=80 + s) for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    out, counts = g.getMatchesAll(cap_per_stream=8)
+    assert list(counts) == [0] * S  # nothing pushed yet
+    for t in range(2):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+    g.matchFeatures(pkg.METHOD_QUAD)
+    per = [g.getMatches(s) for s in range(S)]
+    buf = pkg.pinned_empty((S, max(len(p) for p in per) + 3), pkg.P_MATCH_DTYPE)
+    out, counts = g.getMatchesAll(out=buf)
+    for s in range(S):
+        assert counts[s] == len(per[s]) > 50 and out[s, :counts[s]].tobytes() == per[s].tobytes()
+    with pytest.raises(pkg.VisoHipError) as e:  # too small: true counts still reported through the exception path
+        g.getMatchesAll(cap_per_stream=10)
+    assert e.value.code == pkg.VH_ERR_CAPACITY
+    g.removeOutliers(2)
+    out, counts = g.getMatchesAll(out=buf)
+    for s in range(S):
+        want = g.getMatches(s)
+        assert counts[s] == len(want) and out[s, :counts[s]].tobytes() == want.tobytes()
+    g.close()

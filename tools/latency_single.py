@@ -44,4 +44,13 @@ for S, pinned in ((64, False), (256, False), (256, True)):
     g.synchronize()
     dt = time.perf_counter() - t0
     print(f"group of {S} streams, HOST images ({'page-locked' if pinned else 'pageable'}, H2D inside pushBack): {S * k / dt:.0f} pairs/s")
+    # images in AND matches out (vh_group_get_matches_all) every step
+    mbuf = pkg.pinned_empty((S, 16384), pkg.P_MATCH_DTYPE) if pinned else np.zeros((S, 16384), pkg.P_MATCH_DTYPE)
+    t0 = time.perf_counter(); k = 0
+    for rep in range(2):
+        for t in range(8):
+            g.pushBack(L[t], R[t], dims, False); g.matchFeatures(2); _, cnt = g.getMatchesAll(out=mbuf); k += 1
+    dt = time.perf_counter() - t0
+    print(f"group of {S} streams, HOST images in + all matches out ({'page-locked' if pinned else 'pageable'} buffers, "
+          f"{int(cnt.mean())} matches per pair): {S * k / dt:.0f} pairs/s")
     g.close()
