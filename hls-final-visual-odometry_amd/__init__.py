@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
     "vh_set_stream", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
-    "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_get_features",
+    "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
 )
@@ -123,6 +123,7 @@ def _lib():
             "vh_group_push_back": [vp, vp, vp, i64, vp, i32],
             "vh_group_match_features": [vp, i32], "vh_group_get_matches": [vp, i32, vp, i32, vp],
             "vh_group_get_matches_all": [vp, vp, i32, vp],
+            "vh_group_download_matches_async": [vp, vp, i32, vp], "vh_group_wait_download": [vp],
             "vh_group_get_features": [vp, i32, i32, vp, i32, vp], "vh_group_get_counts": [vp, vp, vp],
             "vh_group_synchronize": [vp], "vh_group_set_stream": [vp, vp],
             "vh_group_profile_enable": [vp, i32], "vh_group_profile_read": [vp, C.c_char_p, vp, vp],
@@ -346,6 +347,17 @@ class StreamGroup:
         counts = np.zeros(self.S, np.int32)
         _check(_lib().vh_group_get_matches_all(self._h, _ptr(out), out.shape[1], _ptr(counts)), "vh_group_get_matches_all")
         return out, counts
+
+    def downloadMatchesAsync(self, out: np.ndarray, counts: np.ndarray):
+        """Start the asynchronous download of all streams' match lists into page-locked
+        `out` [S, cap] / `counts` [S] (pinned_empty); waitDownload() before reading them."""
+        assert out.dtype == P_MATCH_DTYPE and out.ndim == 2 and out.shape[0] == self.S and out.flags.c_contiguous
+        assert counts.dtype == np.int32 and counts.shape == (self.S,) and counts.flags.c_contiguous
+        _check(_lib().vh_group_download_matches_async(self._h, _ptr(out), out.shape[1], _ptr(counts)),
+               "vh_group_download_matches_async")
+
+    def waitDownload(self):
+        _check(_lib().vh_group_wait_download(self._h), "vh_group_wait_download")
 
     def getCounts(self):
         nf = np.zeros((self.S, 4), np.int32)

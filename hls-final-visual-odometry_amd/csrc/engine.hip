@@ -81,6 +81,11 @@ struct Group {
   int32_t stage_slot = 0;
   hipStream_t copy_stream = nullptr;
   size_t stage_bytes = 0;
+  // asynchronous download of the match lists (vh_group_download_matches_async)
+  hipStream_t down_stream = nullptr;
+  hipEvent_t ev_down = nullptr;
+  bool ev_down_valid = false;
+  int32_t last_buf = 0;
   uint8_t *d_half = nullptr;                 // half-resolution images [S*2]
   uint64_t *d_rec = nullptr;
   int32_t *d_chunk_count = nullptr;
@@ -109,6 +114,8 @@ struct Group {
     if (ev_user) (void)hipEventDestroy(ev_user);
     for (int k = 0; k < 2; k++) if (ev_stage[k]) (void)hipEventDestroy(ev_stage[k]);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (ev_down) (void)hipEventDestroy(ev_down);
+    if (down_stream) (void)hipStreamDestroy(down_stream);
     for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); }
     if (post_stream && own_post) (void)hipStreamDestroy(post_stream);
     if (match_stream && !serial) (void)hipStreamDestroy(match_stream);
@@ -119,6 +126,7 @@ struct Group {
     VH_HIP(hipStreamSynchronize(stream));
     VH_HIP(hipStreamSynchronize(match_stream));
     VH_HIP(hipStreamSynchronize(post_stream));
+    VH_HIP(hipStreamSynchronize(down_stream));
     return VH_OK;
   }
 
@@ -126,7 +134,7 @@ struct Group {
     for (void *q : allocs) (void)hipFree(q);
     allocs.clear();
     device_bytes = 0;
-    d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0;
+    d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0; ev_down_valid = false;
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr;
@@ -425,13 +433,36 @@ struct Group {
       }
     }
     { Scope sc(this, "chain", ps); vh_launch_chain(sets, a, method, d_best2[buf], d_chain2[buf], d_mask, epoch, d_mchunk, ps); }
+    // a download of the previous step's lists may still be reading d_matches
+    if (ev_down_valid) VH_HIP(hipStreamWaitEvent(ps, ev_down, 0));
     { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_mchunk, ps); }
     VH_HIP(hipGetLastError());
     VH_HIP(hipEventRecord(ev_post[buf], ps)); ev_post_valid[buf] = true;
     // both slots stay in use until this point of the post stream
     VH_HIP(hipEventRecord(ev_read[pair_cur], ps)); ev_read_valid[pair_cur] = true;
     VH_HIP(hipEventRecord(ev_read[pair_prev], ps)); ev_read_valid[pair_prev] = true;
-    last_method = method; drop_host_matches();
+    last_method = method; drop_host_matches(); last_buf = buf;
+    return VH_OK;
+  }
+
+  // Start the device->host copy of every stream's first cap_per_stream match
+  // records and of the S counts, ordered after the emission of the last step,
+  // and return at once.  One strided transfer: the copy engine moves it while
+  // the next step computes (its emit_matches waits for the download, above).
+  int32_t download_async(vh_p_match *out, int32_t cap_per_stream, int32_t *counts) {
+    if (!out || !counts || cap_per_stream < 1) return VH_ERR_INVALID_ARG;
+    if (!allocated || last_method < 0) return VH_ERR_STATE;
+    VH_HIP(hipStreamWaitEvent(down_stream, ev_post[last_buf], 0));
+    const size_t width = sizeof(vh_p_match) * (size_t)std::min(cap_per_stream, mcap);
+    VH_HIP(hipMemcpy2DAsync(out, sizeof(vh_p_match) * (size_t)cap_per_stream, d_matches, sizeof(vh_p_match) * (size_t)mcap,
+                            width, (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipMemcpyAsync(counts, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipEventRecord(ev_down, down_stream));
+    ev_down_valid = true;
+    return VH_OK;
+  }
+  int32_t wait_download() {
+    if (ev_down_valid) VH_HIP(hipEventSynchronize(ev_down));
     return VH_OK;
   }
 
@@ -682,6 +713,8 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
   ok = ok && hipEventCreateWithFlags(&gq->ev_user, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&gq->ev_stage[k], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&gq->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&gq->down_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&gq->ev_down, hipEventDisableTiming) == hipSuccess;
   if (!ok) { t_last_error = "stream/event creation failed"; delete gq; return VH_ERR_HIP; }
   *out = gq;
   return VH_OK;
@@ -769,6 +802,14 @@ int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32
 int32_t vh_group_get_matches_all(vh_group *g, vh_p_match *out, int32_t cap_per_stream, int32_t *counts) {
   Group *gq = (Group *)g; ENTER(gq);
   return gq->get_matches_all(out, cap_per_stream, counts);
+}
+int32_t vh_group_download_matches_async(vh_group *g, vh_p_match *out, int32_t cap_per_stream, int32_t *counts) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->download_async(out, cap_per_stream, counts);
+}
+int32_t vh_group_wait_download(vh_group *g) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->wait_download();
 }
 int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_t *out12, int32_t cap, int32_t *n) {
   Group *gq = (Group *)g; ENTER(gq);

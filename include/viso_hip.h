@@ -241,6 +241,16 @@ int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32
  * any count exceeds cap_per_stream; the records that fit are still written).
  * `out` in page-locked memory (vh_host_alloc) makes the transfers run at PCIe rate. */
 int32_t vh_group_get_matches_all(vh_group *g, vh_p_match *out, int32_t cap_per_stream, int32_t *counts);
+/* The same without waiting: starts one strided device->host transfer of the first
+ * cap_per_stream records of every stream (whatever their counts; records beyond
+ * counts[s] are stale) plus the S counts, ordered after the last
+ * vh_group_match_features, and returns.  The next step can be issued at once; its
+ * emission waits for this download on the device.  `out` and `counts` must be
+ * page-locked (vh_host_alloc) and stay untouched until vh_group_wait_download
+ * (or vh_group_synchronize) returns.  Host-side post-processing
+ * (vh_group_remove_outliers) is not reflected: these are the device lists. */
+int32_t vh_group_download_matches_async(vh_group *g, vh_p_match *out, int32_t cap_per_stream, int32_t *counts);
+int32_t vh_group_wait_download(vh_group *g);
 int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_t *out12,
                               int32_t cap, int32_t *n);
 /* Per-stream counts of the last step without copying records:

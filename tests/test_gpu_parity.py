@@ -539,3 +539,39 @@ def test_group_get_matches_all(pkg, ob, oracle, gpu):
         want = g.getMatches(s)
         assert counts[s] == len(want) and out[s, :counts[s]].tobytes() == want.tobytes()
     g.close()
+
+
+@pytest.mark.gpu
+def test_group_async_download(pkg, ob, oracle, gpu):
+    """vh_group_download_matches_async: the lists of step t land in page-locked
+    memory while step t+1 is already issued, and equal the synchronous result."""
+    W, H, S, T = 320, 160, 3, 5
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, T, disparity=4 + s, blur=4, seed=90 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(T)] for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    bufs = [pkg.pinned_empty((S, 4096), pkg.P_MATCH_DTYPE) for _ in range(2)]
+    cnts = [pkg.pinned_empty((S,), np.int32) for _ in range(2)]
+    with pytest.raises(pkg.VisoHipError):
+        g.downloadMatchesAsync(bufs[0], cnts[0])  # nothing matched yet
+    pending = None
+    for t in range(T):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+        if t == 0:
+            continue
+        g.matchFeatures(pkg.METHOD_QUAD)
+        g.waitDownload()
+        if pending is not None:
+            tt, b = pending
+            for s in range(S):
+                want = oracle.matching(po, dims, 2, F[s][tt - 1][0], F[s][tt - 1][1], F[s][tt][0], F[s][tt][1])
+                assert cnts[b][s] == len(want) > 50 and bufs[b][s, :len(want)].tobytes() == want.tobytes()
+        g.downloadMatchesAsync(bufs[t % 2], cnts[t % 2])
+        pending = (t, t % 2)
+    g.waitDownload()
+    tt, b = pending
+    for s in range(S):
+        want = oracle.matching(po, dims, 2, F[s][tt - 1][0], F[s][tt - 1][1], F[s][tt][0], F[s][tt][1])
+        assert cnts[b][s] == len(want) and bufs[b][s, :len(want)].tobytes() == want.tobytes()
+    g.close()

@@ -53,4 +53,18 @@ for S, pinned in ((64, False), (256, False), (256, True)):
     dt = time.perf_counter() - t0
     print(f"group of {S} streams, HOST images in + all matches out ({'page-locked' if pinned else 'pageable'} buffers, "
           f"{int(cnt.mean())} matches per pair): {S * k / dt:.0f} pairs/s")
+    if pinned:
+        # the same, pipelined: the download of step k runs while step k+1 is uploaded and computed
+        mb = [pkg.pinned_empty((S, 10240), pkg.P_MATCH_DTYPE) for _ in range(2)]
+        cb = [pkg.pinned_empty((S,), np.int32) for _ in range(2)]
+        t0 = time.perf_counter(); k = 0
+        for rep in range(2):
+            for t in range(8):
+                g.pushBack(L[t], R[t], dims, False); g.matchFeatures(2)
+                g.waitDownload()                       # step k-1's lists are now in mb[(k-1) % 2]
+                g.downloadMatchesAsync(mb[k % 2], cb[k % 2]); k += 1
+        g.waitDownload()
+        dt = time.perf_counter() - t0
+        print(f"group of {S} streams, HOST images in + all matches out, asynchronous download "
+              f"({int(cb[(k - 1) % 2].mean())} matches per pair): {S * k / dt:.0f} pairs/s")
     g.close()
