@@ -215,7 +215,11 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
       };
       if (interior) {
         // [0, ja): v test, [ja, jb): no test, [jb, mcnt): v test
-        const int32_t ja = min(max(pa0 - pc, 0), mcnt), jb = min(max(pa1 - pc, ja), mcnt);
+        // (the untested range is shrunk inward to multiples of the unroll factor:
+        // testing a few candidates that would not need it is always valid, and only
+        // the chunk's tail is then left to the one-candidate loop)
+        const int32_t ja = min((min(max(pa0 - pc, 0), mcnt) + CPI - 1) & ~(CPI - 1), mcnt);
+        const int32_t jb = max(min(max(pa1 - pc, 0), mcnt) & ~(CPI - 1), ja);
         run(std::integral_constant<int, 1>{}, ja);
         run(std::integral_constant<int, 0>{}, jb);
         run(std::integral_constant<int, 1>{}, mcnt);
