@@ -92,6 +92,39 @@ def cpu_baseline(ob, frames, dims, budget_s: float, over=None):
     return pairs / dt, pairs, dt, results
 
 
+def cpu_baseline_threads(ob, frames, dims, budget_s: float, over, n_threads: int):
+    """The same CPU path on n_threads host threads, one camera stream each (the
+    C calls release the GIL): what the host of this GPU does on the workload when
+    every core of its share is put on it."""
+    import threading
+    T = frames.shape[0]
+    done = [0] * n_threads
+    t_end = time.perf_counter() + budget_s
+
+    def work(i):
+        o = ob.Oracle()
+        p = ob.Params.default(**(over or {}))
+        s = i % frames.shape[2]
+        prev, k = None, 0
+        while time.perf_counter() < t_end or done[i] < 1:
+            t = k % T
+            cur = [o.compute_features(p, frames[t, c, s], dims)[1] for c in (0, 1)]
+            if prev is not None:
+                o.matching(p, dims, 2, prev[0], prev[1], cur[0], cur[1])
+                done[i] += 1
+            prev = cur
+            k += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    return sum(done) / dt, sum(done), dt
+
+
 def in_window_pairs(q, c, radius: int) -> int:
     """(query, candidate) pairs findMatch must evaluate for a flow pass: same
     class, |du| <= radius, |dv| <= radius (src/matcher.cpp:237-249)."""
@@ -300,6 +333,11 @@ def main():
             out["cpu_baseline"] = {"value": rate, "unit": "pairs/s", "cores": 1, "kind": "port",
                                    "sample": f"{n_pairs} consecutive stereo pairs of stream 0 (detect 2 images + quad match each), "
                                              f"{secs:.1f} s, oracle/viso_oracle.c single thread"}
+            nthr = max(1, min(len(os.sched_getaffinity(0)), S, 16))  # 16 = the host-core share of one GPU on this pool
+            if nthr > 1:
+                mrate, mpairs, msecs = cpu_baseline_threads(ob, frames_np, dims, min(args.cpu_seconds, 6.0), wl["params"], nthr)
+                out["cpu_baseline_all_cores"] = {"value": mrate, "unit": "pairs/s", "cores": nthr, "kind": "port",
+                                                 "sample": f"{mpairs} stereo pairs over {nthr} streams, one host thread each, {msecs:.1f} s"}
             # the oracle as checker: stream 0's last GPU step must equal the CPU result for the same frames
             o = ob.Oracle(); p = ob.Params.default(**wl["params"])
             prev_t = (last - 1) % T
