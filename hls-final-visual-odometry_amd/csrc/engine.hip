@@ -322,8 +322,8 @@ struct Group {
     // beside the previous frame's flow search, was measured on MI355X and loses
     // 9 % (n=2) to 34 % (n=8): fewer, larger launches win.
     const int32_t ncam = dI2 ? 2 : 1;
-    int32_t nsub = 1;
-    if (const char *ev = getenv("VH_SUBBATCH")) nsub = std::max(1, std::min(atoi(ev), S));
+    static const int subbatch = [] { const char *ev = getenv("VH_SUBBATCH"); return ev ? atoi(ev) : 1; }();
+    const int32_t nsub = std::max(1, std::min(subbatch, S));
     const int32_t ssub = (S + nsub - 1) / nsub;
     for (int32_t s0 = 0; s0 < S; s0 += ssub) {
       const int32_t sn = std::min(ssub, S - s0);
