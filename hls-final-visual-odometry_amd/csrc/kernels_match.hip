@@ -12,10 +12,13 @@
 //    bin-ordered queries (of one class; of one (class, u-bin) column when the v
 //    window does not span the image).  The candidate stream is then wave-uniform:
 //    all 64 lanes walk the same bin range, candidates are staged 64 at a time in
-//    a wave-private LDS chunk and broadcast-read, and the SAD is 8 v_sad_u8 per
-//    lane and query with no cross-lane reduction at all.  Positions in bin order ARE the reference's visiting order, so its
+//    a wave-private LDS chunk and broadcast-read, and the SAD is 8 v_sad_u8 /
+//    v_sad_hi_u8 per lane and query with no cross-lane reduction at all.
+//    Positions in bin order ARE the reference's visiting order, so its
 //    first-minimum tie-break (strict `<`, src/matcher.cpp:264) is the minimum of
-//    the key (SAD << 19 | position), whatever order candidates arrive in.
+//    the key (SAD << 19 | position) -- or (SAD << 16 | position - class base),
+//    which the v_sad_hi_u8 chain produces by itself -- whatever order
+//    candidates arrive in.
 //  * Each lane applies the reference's accept test on its own window
 //    (src/matcher.cpp:249); the wave only walks the union of its lanes' bin
 //    ranges (src/matcher.cpp:237-240), which never changes a lane's result
