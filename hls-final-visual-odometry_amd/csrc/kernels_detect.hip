@@ -12,10 +12,11 @@
 //                 (+halo) is staged in LDS once, the blob and checkerboard
 //                 responses are produced into LDS by a separable sliding-window
 //                 pass and never touch HBM; NMS runs on the LDS tile: block
-//                 extrema per lane, then "candidate == minimum of its clipped
-//                 (2n+1)^2 window" via a packed vertical window-min/max pass --
-//                 equivalent to the reference's per-candidate dominance scan --
-//                 and leaves 8 bytes per block (4 x u16 position codes).
+//                 extrema and threshold per lane, then, for the queued few
+//                 that passed it, "candidate == minimum of its clipped
+//                 (2n+1)^2 window" -- equivalent to the reference's
+//                 per-candidate dominance scan -- and leaves 8 bytes per block
+//                 (4 x u16 position codes).
 //                 detect_nms_fast<N> (nms_n 1..4, 4-byte aligned rows) is the
 //                 compile-time specialised form; detect_nms_kernel is the
 //                 generic one (any nms_n, any stride) with the literal scan.
