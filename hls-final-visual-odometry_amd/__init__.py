@@ -37,10 +37,10 @@ ABI_SYMBOLS = (
     "vh_abi_version", "vh_device_count", "vh_error_string", "vh_last_error", "vh_default_params",
     "vh_create", "vh_create_ex", "vh_destroy", "vh_set_intrinsics", "vh_push_back", "vh_push_back_device",
     "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
-    "vh_set_stream", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
+    "vh_set_stream", "vh_clear_stream", "vh_stream_wait_images", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
     "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
-    "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_profile_enable",
+    "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_clear_stream", "vh_group_stream_wait_images", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
 )
 
@@ -109,7 +109,7 @@ def _lib():
             "vh_push_back": [vp, vp, vp, vp, i32], "vh_push_back_device": [vp, vp, vp, vp, i32],
             "vh_match_features": [vp, i32, vp], "vh_bucket_features": [vp, i32, f32, f32],
             "vh_get_matches": [vp, vp, i32, vp], "vh_get_features": [vp, i32, vp, i32, vp],
-            "vh_synchronize": [vp], "vh_set_stream": [vp, vp],
+            "vh_synchronize": [vp], "vh_set_stream": [vp, vp], "vh_clear_stream": [vp], "vh_stream_wait_images": [vp, vp],
             "vh_remove_outliers": [vp], "vh_remove_outliers_pm": [vp, i32, vp], "vh_group_remove_outliers": [vp, i32],
             "vh_host_alloc": [i32, C.c_size_t, vp], "vh_host_free": [vp],
             "vh_compute_features": [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp],
@@ -125,7 +125,8 @@ def _lib():
             "vh_group_get_matches_all": [vp, vp, i32, vp],
             "vh_group_download_matches_async": [vp, vp, i32, vp], "vh_group_wait_download": [vp],
             "vh_group_get_features": [vp, i32, i32, vp, i32, vp], "vh_group_get_counts": [vp, vp, vp],
-            "vh_group_synchronize": [vp], "vh_group_set_stream": [vp, vp],
+            "vh_group_synchronize": [vp], "vh_group_set_stream": [vp, vp], "vh_group_clear_stream": [vp],
+            "vh_group_stream_wait_images": [vp, vp],
             "vh_group_profile_enable": [vp, i32], "vh_group_profile_read": [vp, C.c_char_p, vp, vp],
             "vh_group_profile_reset": [vp],
         }
@@ -265,7 +266,16 @@ class Matcher:
         _check(_lib().vh_synchronize(self._h), "vh_synchronize")
 
     def setStream(self, hip_stream: int | None):
-        _check(_lib().vh_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None), "vh_set_stream")
+        """Order every pushBack after `hip_stream` (a hipStream_t handle; 0 is the legacy
+        default stream, a stream like any other); None removes the ordering."""
+        if hip_stream is None:
+            _check(_lib().vh_clear_stream(self._h), "vh_clear_stream")
+        else:
+            _check(_lib().vh_set_stream(self._h, C.c_void_p(int(hip_stream))), "vh_set_stream")
+
+    def streamWaitImages(self, hip_stream: int):
+        """Make `hip_stream` wait (device side) until the last pushBackDevice's images were consumed."""
+        _check(_lib().vh_stream_wait_images(self._h, C.c_void_p(int(hip_stream))), "vh_stream_wait_images")
 
 
 # ------------------------------------------------------------------ S streams in lock step
@@ -369,8 +379,16 @@ class StreamGroup:
         _check(_lib().vh_group_synchronize(self._h), "vh_group_synchronize")
 
     def setStream(self, hip_stream: int | None):
-        _check(_lib().vh_group_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None),
-               "vh_group_set_stream")
+        """Order every pushBack after `hip_stream` (a hipStream_t handle; 0 is the legacy
+        default stream, a stream like any other); None removes the ordering."""
+        if hip_stream is None:
+            _check(_lib().vh_group_clear_stream(self._h), "vh_group_clear_stream")
+        else:
+            _check(_lib().vh_group_set_stream(self._h, C.c_void_p(int(hip_stream))), "vh_group_set_stream")
+
+    def streamWaitImages(self, hip_stream: int):
+        """Make `hip_stream` wait (device side) until the last pushBackDevice's images were consumed."""
+        _check(_lib().vh_group_stream_wait_images(self._h, C.c_void_p(int(hip_stream))), "vh_group_stream_wait_images")
 
     def profileEnable(self, on: bool = True):
         _check(_lib().vh_group_profile_enable(self._h, 1 if on else 0), "vh_group_profile_enable")

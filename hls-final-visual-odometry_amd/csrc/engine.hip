@@ -61,6 +61,10 @@ struct Group {
   hipEvent_t ev_read[3] = {nullptr, nullptr, nullptr};  // last match that read the slot
   bool ev_read_valid[3] = {false, false, false};
   hipEvent_t ev_user = nullptr;
+  bool user_stream_set = false;  // handle 0 is a real stream (the legacy default stream): "unset" is a flag, not a value
+  bool failed = false;           // the last push did not complete: no matching until the next successful one
+  int32_t *d_overflow = nullptr; // [S] 1: a feature set of the stream's last match held more records than cap
+  int32_t *h_overflow = nullptr; // page-locked mirror for the asynchronous download
   int32_t pair_prev = 1;
   bool serial = false, own_post = false;
 
@@ -138,7 +142,8 @@ struct Group {
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr;
-    d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr;
+    d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
+    if (h_overflow) { (void)hipHostFree(h_overflow); h_overflow = nullptr; }
     allocated = false;
   }
 
@@ -243,10 +248,13 @@ struct Group {
     if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 255) / 256), true))) return rc;
     if ((rc = dmalloc((uint8_t **)&d_matches, (size_t)S * mcap * sizeof(vh_p_match), false))) return rc;
     if ((rc = dmalloc(&d_match_count, (size_t)S, true))) return rc;
+    if ((rc = dmalloc(&d_overflow, (size_t)S, true))) return rc;
+    VH_HIP(hipHostMalloc((void **)&h_overflow, sizeof(int32_t) * (size_t)S, hipHostMallocDefault));
+    memset(h_overflow, 0, sizeof(int32_t) * (size_t)S);
     if (p.half_resolution)
       if ((rc = dmalloc(&d_half, 2 * (size_t)S * g.bplm * g.Hm, false))) return rc;
     allocated = true;
-    pair_cur = 0; pair_prev = 1; frames = 0; epoch = 0; last_method = -1;
+    pair_cur = 0; pair_prev = 1; frames = 0; epoch = 0; last_method = -1; failed = false;
     host_matches.assign((size_t)S, {}); host_filtered.assign((size_t)S, 0);
     for (int k = 0; k < 3; k++) ev_read_valid[k] = false;
     ev_post_valid[0] = ev_post_valid[1] = false; match_seq = 0;
@@ -297,10 +305,23 @@ struct Group {
     return VH_OK;
   }
 
+  // pushBack: a failure after the ring has rotated leaves the new slot half written;
+  // the roles are put back and the handle refuses to match (VH_ERR_STATE) until a
+  // later push has succeeded.
   int32_t push_device(const void *dI1, const void *dI2, int64_t stride, const int32_t d[3], int32_t replace) {
     if (!dI1 || !d) return VH_ERR_INVALID_ARG;
     int32_t rc = ensure(d);
     if (rc != VH_OK) return rc;
+    const int32_t old_cur = pair_cur, old_prev = pair_prev;
+    const int64_t old_frames = frames;
+    rc = push_device_queued(dI1, dI2, stride, d, replace);
+    if (rc != VH_OK) { pair_cur = old_cur; pair_prev = old_prev; frames = old_frames; failed = true; }
+    else failed = false;
+    return rc;
+  }
+
+  int32_t push_device_queued(const void *dI1, const void *dI2, int64_t stride, const int32_t d[3], int32_t replace) {
+    int32_t rc = VH_OK;
     if (!replace && frames > 0) {  // ring buffer shift (matcher.cpp:64-79): prev <- cur, cur <- the third slot
       const int32_t fresh = 3 - pair_cur - pair_prev;
       pair_prev = pair_cur;
@@ -311,7 +332,7 @@ struct Group {
     const int32_t set0 = pair_cur * 2 * S, nsets = 2 * S;
     // order after the caller's stream (image producers) and after the last match
     // that still reads the slot we are about to overwrite
-    if (user_stream) {
+    if (user_stream_set) {
       VH_HIP(hipEventRecord(ev_user, user_stream));
       VH_HIP(hipStreamWaitEvent(stream, ev_user, 0));
     }
@@ -405,7 +426,7 @@ struct Group {
 
   int32_t match(int32_t method) {
     if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
-    if (!allocated) return VH_ERR_STATE;
+    if (!allocated || failed) return VH_ERR_STATE;
     const VhMatchArgs a = match_args(method);
     hipStream_t ms = match_stream, ps = post_stream;
     const int32_t buf = (int32_t)(match_seq++ & 1);
@@ -435,7 +456,7 @@ struct Group {
     { Scope sc(this, "chain", ps); vh_launch_chain(sets, a, method, d_best2[buf], d_chain2[buf], d_mask, epoch, d_mchunk, ps); }
     // a download of the previous step's lists may still be reading d_matches
     if (ev_down_valid) VH_HIP(hipStreamWaitEvent(ps, ev_down, 0));
-    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_mchunk, ps); }
+    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, ps); }
     VH_HIP(hipGetLastError());
     VH_HIP(hipEventRecord(ev_post[buf], ps)); ev_post_valid[buf] = true;
     // both slots stay in use until this point of the post stream
@@ -457,12 +478,15 @@ struct Group {
     VH_HIP(hipMemcpy2DAsync(out, sizeof(vh_p_match) * (size_t)cap_per_stream, d_matches, sizeof(vh_p_match) * (size_t)mcap,
                             width, (size_t)S, hipMemcpyDeviceToHost, down_stream));
     VH_HIP(hipMemcpyAsync(counts, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
     VH_HIP(hipEventRecord(ev_down, down_stream));
     ev_down_valid = true;
     return VH_OK;
   }
   int32_t wait_download() {
-    if (ev_down_valid) VH_HIP(hipEventSynchronize(ev_down));
+    if (!ev_down_valid) return VH_OK;
+    VH_HIP(hipEventSynchronize(ev_down));
+    for (int32_t s = 0; s < S; s++) if (h_overflow[s]) return VH_ERR_CAPACITY;
     return VH_OK;
   }
 
@@ -476,8 +500,9 @@ struct Group {
       if (k) memcpy(out, host_matches[s].data(), sizeof(vh_p_match) * (size_t)k);
       return *n > capo ? VH_ERR_CAPACITY : VH_OK;
     }
-    int32_t cnt = 0;
+    int32_t cnt = 0, ov = 0;
     VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(&ov, d_overflow + s, sizeof(int32_t), hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipStreamSynchronize(post_stream));
     *n = cnt;
     const int32_t k = std::min(std::min(cnt, mcap), capo);
@@ -486,7 +511,9 @@ struct Group {
                             sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, post_stream));
       VH_HIP(hipStreamSynchronize(post_stream));
     }
-    return (cnt > capo || cnt > mcap) ? VH_ERR_CAPACITY : VH_OK;
+    // ov: a feature set of this match exceeded the feature capacity (the records beyond
+    // it were dropped, so the list above comes from a truncated set)
+    return (cnt > capo || cnt > mcap || ov) ? VH_ERR_CAPACITY : VH_OK;
   }
 
   int32_t get_features(int32_t s, int32_t which, int32_t *out12, int32_t capo, int32_t *n) {
@@ -532,8 +559,10 @@ struct Group {
     for (int32_t s = 0; s < S; s++) counts[s] = 0;
     if (!allocated || last_method < 0) return VH_OK;
     VH_HIP(hipMemcpyAsync(counts, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipStreamSynchronize(post_stream));
     bool over = false;
+    for (int32_t s = 0; s < S; s++) over = over || h_overflow[s] != 0;
     for (int32_t s = 0; s < S; s++) {
       if (host_filtered[s]) {
         counts[s] = (int32_t)host_matches[s].size();
@@ -562,7 +591,7 @@ struct Group {
     if (rc != VH_OK && rc != VH_ERR_CAPACITY) return rc;
     if (n > mcap) return VH_ERR_CAPACITY;
     std::vector<vh_p_match> pm((size_t)n);
-    if (n && (rc = get_matches(s, pm.data(), n, &n))) return rc;
+    if ((rc = get_matches(s, n ? pm.data() : nullptr, n, &n))) return rc;  // VH_ERR_CAPACITY: a feature set overflowed
     host_matches[s].swap(pm);
     host_filtered[s] = 1;
     return VH_OK;
@@ -656,7 +685,7 @@ void bucket_host(std::vector<vh_p_match> &pm, int32_t max_features, float bw, fl
 int32_t check_params(const vh_params *p) {
   if (!p) return VH_ERR_INVALID_ARG;
   if (p->nms_n < 1 || p->nms_n > 32 || p->match_binsize < 1 || p->match_radius < 0 || p->match_disp_tolerance < 0 ||
-      p->match_radius > 16384 || p->nms_tau < 0)
+      p->match_radius > 16384 || p->match_disp_tolerance > 16384 || p->nms_tau < 0)  // the accept test packs 2*tolerance into 16 bits
     return VH_ERR_UNSUPPORTED;
   return VH_OK;
 }
@@ -827,7 +856,22 @@ int32_t vh_group_set_stream(vh_group *g, void *hip_stream) {
   Group *gq = (Group *)g; ENTER(gq);
   int32_t rc = gq->sync_all();
   if (rc) return rc;
-  gq->user_stream = (hipStream_t)hip_stream;  // NULL: no external ordering
+  gq->user_stream = (hipStream_t)hip_stream;  // handle 0 is the legacy default stream, a stream like any other
+  gq->user_stream_set = true;
+  return VH_OK;
+}
+int32_t vh_group_clear_stream(vh_group *g) {
+  Group *gq = (Group *)g; ENTER(gq);
+  int32_t rc = gq->sync_all();
+  if (rc) return rc;
+  gq->user_stream = nullptr; gq->user_stream_set = false;
+  return VH_OK;
+}
+int32_t vh_group_stream_wait_images(vh_group *g, void *hip_stream) {
+  Group *gq = (Group *)g; ENTER(gq);
+  if (!gq->allocated) return VH_OK;  // nothing pushed yet: nothing reads any image
+  // the detection (and indexing) of the last pushed frame is the last reader of its images
+  VH_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, gq->ev_det[gq->pair_cur], 0));
   return VH_OK;
 }
 int32_t vh_group_profile_enable(vh_group *g, int32_t on) {
@@ -917,6 +961,8 @@ int32_t vh_host_free(void *ptr) {
 }
 int32_t vh_synchronize(vh_matcher *m) { return vh_group_synchronize((vh_group *)m); }
 int32_t vh_set_stream(vh_matcher *m, void *hip_stream) { return vh_group_set_stream((vh_group *)m, hip_stream); }
+int32_t vh_clear_stream(vh_matcher *m) { return vh_group_clear_stream((vh_group *)m); }
+int32_t vh_stream_wait_images(vh_matcher *m, void *hip_stream) { return vh_group_stream_wait_images((vh_group *)m, hip_stream); }
 
 // ---- stateless primitives ----------------------------------------------------
 int32_t vh_filters(int32_t device, const uint8_t *I, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,

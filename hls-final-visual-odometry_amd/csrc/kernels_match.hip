@@ -547,7 +547,7 @@ __global__ void flow_keep_kernel(VhSets s, VhMatchArgs a, int4 *__restrict__ cha
 __global__ void __launch_bounds__(256)
 emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restrict__ chain,
                     float *__restrict__ matches, int32_t mcap, int32_t *__restrict__ match_count,
-                    const int32_t *__restrict__ mchunk, int32_t nchm) {
+                    int32_t *__restrict__ overflow, const int32_t *__restrict__ mchunk, int32_t nchm) {
   __shared__ int32_t sWave[4];
   __shared__ int32_t sBase;
   const int32_t chunk = blockIdx.x, stream = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -604,7 +604,18 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
     o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
     o[2] = make_uint4(rec[8], rec[9], rec[10], rec[11]);
   }
-  if (chunk == nchm - 1 && tid == 0) match_count[stream] = base + tot;
+  if (chunk == nchm - 1 && tid == 0) {
+    match_count[stream] = base + tot;
+    // a set this method read held more features than the capacity: the matching ran on
+    // its first `cap` records only, which the host reports as VH_ERR_CAPACITY
+    int32_t ov = 0;
+#pragma unroll
+    for (int32_t r = 0; r < 4; r++) {
+      const bool used = method == 2 || r == 2 || (method == 0 && r == 0) || (method == 1 && r == 3);
+      if (used && s.count[sets[r]] > s.cap) ov = 1;
+    }
+    overflow[stream] = ov;
+  }
 }
 
 }  // namespace
@@ -661,9 +672,9 @@ void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, cons
     hipLaunchKernelGGL(flow_keep_kernel, grid, dim3(256), 0, st, s, a, chain, (const uint32_t *)mask, epoch, mchunk, nchm);
 }
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
-                            void *matches, int32_t mcap, int32_t *match_count, const int32_t *mchunk,
-                            hipStream_t st) {
+                            void *matches, int32_t mcap, int32_t *match_count, int32_t *overflow,
+                            const int32_t *mchunk, hipStream_t st) {
   const int32_t nchm = (s.cap + 255) / 256;
   hipLaunchKernelGGL(emit_matches_kernel, dim3(nchm, a.S), dim3(256), 0, st, s, a, method, chain,
-                     (float *)matches, mcap, match_count, mchunk, nchm);
+                     (float *)matches, mcap, match_count, overflow, mchunk, nchm);
 }

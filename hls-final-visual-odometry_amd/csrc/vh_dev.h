@@ -143,7 +143,7 @@ void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, 
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st);
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
-                            void *matches, int32_t mcap, int32_t *match_count, const int32_t *mchunk,
-                            hipStream_t st);
+                            void *matches, int32_t mcap, int32_t *match_count, int32_t *overflow,
+                            const int32_t *mchunk, hipStream_t st);
 
 #endif

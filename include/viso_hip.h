@@ -93,9 +93,14 @@ void vh_default_params(vh_params *p);
 /* ---- one stream: the Matcher surface ----------------------------------- */
 
 /* Matcher::Matcher(parameters) (src/matcher.cpp:32-41) on HIP device `device`.
- * Envelope: 1 <= nms_n <= 64, match_binsize >= 1, match_radius >= 0,
+ * Envelope (VH_ERR_UNSUPPORTED outside): 1 <= nms_n <= 32, match_binsize >= 1,
+ * 0 <= match_radius <= 16384, 0 <= match_disp_tolerance <= 16384, nms_tau >= 0,
  * images up to 16384 x 16384.  max_features/max_matches = 0 select the
- * worst-case capacity for the pushed image size (4 per NMS block). */
+ * worst-case capacity for the pushed image size (4 per NMS block).
+ * When a pushed image yields more features than the capacity, the records
+ * beyond it are dropped, matching runs on the truncated sets, and
+ * vh_get_matches / vh_group_get_matches(_all) / vh_group_wait_download return
+ * VH_ERR_CAPACITY (vh_get_features reports the true count). */
 int32_t vh_create(const vh_params *p, int32_t device, vh_matcher **out);
 int32_t vh_create_ex(const vh_params *p, int32_t device, int32_t max_features,
                      int32_t max_matches, vh_matcher **out);
@@ -163,10 +168,19 @@ int32_t vh_synchronize(vh_matcher *m);
 /* Order this handle's work after a caller-owned hipStream_t (e.g. the stream
  * that produces the device images, torch's current stream): every pushBack
  * first waits for what that stream has been given so far.  The work itself runs
- * on the handle's internal streams (detection of frame t+1 overlaps matching of
- * frame t); results are complete after vh_synchronize / vh_get_*.  NULL = no
- * external ordering. */
+ * on the handle's internal (non-blocking) streams -- detection of frame t+1
+ * overlaps matching of frame t -- and results are complete after
+ * vh_synchronize / vh_get_*.  The handle 0 (NULL) is the legacy default
+ * stream and is ordered after like any other stream; without a set stream
+ * (the initial state, or after vh_clear_stream) a pushBack is ordered after
+ * nothing, and images produced on ANY stream, the default one included, must
+ * be complete (hipStreamSynchronize) before vh_push_back_device. */
 int32_t vh_set_stream(vh_matcher *m, void *hip_stream);
+int32_t vh_clear_stream(vh_matcher *m);
+/* The reverse ordering: make `hip_stream` wait (on the device, without
+ * blocking the host) until the images handed to the last vh_push_back_device
+ * have been consumed, so that work queued on it afterwards may overwrite them. */
+int32_t vh_stream_wait_images(vh_matcher *m, void *hip_stream);
 
 /* ---- stateless primitives (private members of the reference's Matcher) -- */
 
@@ -258,6 +272,8 @@ int32_t vh_group_get_features(vh_group *g, int32_t stream, int32_t which, int32_
 int32_t vh_group_get_counts(vh_group *g, int32_t *n_features, int32_t *n_matches);
 int32_t vh_group_synchronize(vh_group *g);
 int32_t vh_group_set_stream(vh_group *g, void *hip_stream);
+int32_t vh_group_clear_stream(vh_group *g);
+int32_t vh_group_stream_wait_images(vh_group *g, void *hip_stream);
 
 /* Kernel timing (HIP events recorded on the group's stream around every
  * kernel launch while enabled).  vh_group_profile_read returns the
