@@ -62,6 +62,11 @@ def test_argument_validation_needs_no_gpu(pkg):
     h = C.c_void_p()
     bad = pkg.Params.default(nms_n=0)
     assert lib.vh_create(C.byref(bad), 0, C.byref(h)) == pkg.VH_ERR_UNSUPPORTED
+    # the documented envelope (include/viso_hip.h, vh_create) is what check_params enforces
+    for over in ({"nms_n": 33}, {"match_disp_tolerance": 16385}, {"match_radius": 16385}, {"match_binsize": 0},
+                 {"nms_tau": -1}, {"match_radius": -1}, {"match_disp_tolerance": -1}):
+        assert lib.vh_create(C.byref(pkg.Params.default(**over)), 0, C.byref(h)) == pkg.VH_ERR_UNSUPPORTED, over
+    assert "nms_n <= 32" in open(os.path.join(pkg.INCLUDE, "viso_hip.h")).read()
     assert lib.vh_create(None, 0, C.byref(h)) == pkg.VH_ERR_INVALID_ARG
     n = C.c_int32()
     assert lib.vh_get_matches(None, None, 0, C.byref(n)) == pkg.VH_ERR_INVALID_ARG

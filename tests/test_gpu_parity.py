@@ -575,3 +575,91 @@ def test_group_async_download(pkg, ob, oracle, gpu):
         want = oracle.matching(po, dims, 2, F[s][tt - 1][0], F[s][tt - 1][1], F[s][tt][0], F[s][tt][1])
         assert cnts[b][s] == len(want) and bufs[b][s, :len(want)].tobytes() == want.tobytes()
     g.close()
+
+
+# ------------------------------------------------ round 2: the bench's own entry points, stream ordering, overflow
+@pytest.mark.gpu
+@pytest.mark.parametrize("producer", ["side", "default"])
+def test_group_push_back_device_orders_after_producer_stream(producer, gpu):
+    """vh_group_push_back_device + vh_group_set_stream, the path bench.py times, driven from
+    torch tensors produced on a torch stream: tests/stream_order_case.py (a process of its own,
+    because torch must load its HIP runtime before libviso_hip.so is mapped -- as in bench.py --
+    for the two to share one runtime and hence stream handles)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stream_order_case.py"), producer],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "stream-order ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_feature_capacity_overflow_is_reported_on_the_match_path(pkg, ob, oracle, gpu):
+    """max_features below the feature count: the sets are truncated, and every way of
+    fetching the matches says VH_ERR_CAPACITY instead of silently returning a list
+    matched on truncated sets."""
+    W, H, S = 320, 160, 2
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seq = pkg.synth.stereo_sequence(W, H, 2, disparity=5, blur=4, seed=7)
+    n_full = len(oracle.compute_features(ob.Params.default(), seq[1][0], dims)[1])
+    assert n_full > 400
+    m = pkg.Matcher(pkg.Params.default(), max_features=256, max_matches=4096, outlier_removal=False)
+    for l, r in seq:
+        m.pushBack(l, r, dims, False)
+    for method in (0, 1, 2):
+        m.matchFeatures(method)
+        n = C.c_int32(0)
+        buf = np.zeros(4096, pkg.P_MATCH_DTYPE)
+        rc = pkg._lib().vh_get_matches(m._h, buf.ctypes.data_as(C.c_void_p), 4096, C.byref(n))
+        assert rc == pkg.VH_ERR_CAPACITY and 0 <= n.value <= 256
+        with pytest.raises(pkg.VisoHipError) as e:
+            m.getMatches()
+        assert e.value.code == pkg.VH_ERR_CAPACITY
+    m.close()
+    g = pkg.StreamGroup(S, pkg.Params.default(), max_features=256, max_matches=4096)
+    for l, r in seq:
+        g.pushBack(np.stack([l] * S), np.stack([r] * S), dims, False)
+    g.matchFeatures(pkg.METHOD_QUAD)
+    with pytest.raises(pkg.VisoHipError) as e:
+        g.getMatchesAll(cap_per_stream=4096)
+    assert e.value.code == pkg.VH_ERR_CAPACITY
+    out = pkg.pinned_empty((S, 4096), pkg.P_MATCH_DTYPE); cnt = pkg.pinned_empty((S,), np.int32)
+    g.downloadMatchesAsync(out, cnt)
+    with pytest.raises(pkg.VisoHipError) as e:
+        g.waitDownload()
+    assert e.value.code == pkg.VH_ERR_CAPACITY
+    g.close()
+    # a capacity that fits reports nothing
+    m = pkg.Matcher(pkg.Params.default(), max_features=n_full + 64, max_matches=4096, outlier_removal=False)
+    for l, r in seq:
+        m.pushBack(l, r, dims, False)
+    m.matchFeatures(2)
+    assert len(m.getMatches()) > 50
+    m.close()
+
+
+@pytest.mark.gpu
+def test_4k_stereo_quad_small_bins(pkg, ob, oracle, gpu):
+    """configs[4] as BASELINE states it: a 3840x2160 STEREO pair, nms_n=3, match_binsize=25,
+    quad match.  Features exact vs the oracle on all four images, both stereo-pass tables
+    exact (vh_match_all(flow=False): 1p->2p and 2c->1c), the flow passes and the chain through
+    the size-independent properties (circle closure re-derived with the oracle's findMatch)."""
+    W, H = 3840, 2160
+    dims = [W, H, 3840]
+    over = {"nms_n": 3, "match_binsize": 25}
+    p, po = pkg.Params.default(**over), ob.Params.default(**over)
+    seq = pkg.synth.stereo_sequence(W, H, 2, disparity=14, seed=5)
+    m = pkg.Matcher(p, outlier_removal=False)
+    for l, r in seq:
+        m.pushBack(l, r, dims, False)
+    m.matchFeatures(pkg.METHOD_QUAD)
+    got = m.getMatches()
+    f = [m.getFeatures(k) for k in range(4)]
+    m.close()
+    want_f = feats_for(oracle, po, dims, (seq[0][0], seq[0][1], seq[1][0], seq[1][1]))
+    for a, b in zip(f, want_f):
+        assert np.array_equal(a, b)
+    assert min(len(x) for x in f) > 100000 and len(got) > 80000
+    assert np.array_equal(pkg.match_all(p, dims, f[0], f[1], flow=False), oracle.match_all(po, dims, f[0], f[1], flow=False))
+    assert np.array_equal(pkg.match_all(p, dims, f[3], f[2], flow=False), oracle.match_all(po, dims, f[3], f[2], flow=False))
+    _check_match_properties(pkg, oracle, po, dims, f, got, 2, np.random.default_rng(4), 200)
+    ok = (got["u1p"] - got["u2p"] == 14) & (got["u1c"] - got["u2c"] == 14)
+    assert ok.mean() > 0.9
