@@ -208,11 +208,12 @@ struct Group {
     sets = VhSets{};
     sets.cap = cap;
     sets.binsize = p.match_binsize;
-    sets.inv_binsize = (uint32_t)(((1ull << 32) + p.match_binsize - 1) / p.match_binsize);
+    // exact for 0 <= x <= 32768 (every coordinate +- radius) when binsize <= 32768; a larger bin holds every x: quotient 0
+    sets.inv_binsize = p.match_binsize > 32768 ? 0u : (uint32_t)(((1ull << 32) + p.match_binsize - 1) / p.match_binsize);
     sets.ubn = (dims[0] + p.match_binsize - 1) / p.match_binsize;  // ceil(W/binsize), matcher.cpp:282-283
     sets.vbn = (dims[1] + p.match_binsize - 1) / p.match_binsize;
     sets.nbins = 4 * sets.ubn * sets.vbn;
-    sets.max_tiles = cap / 64 + 4 * sets.ubn + 1;
+    sets.max_tiles = cap / VH_TILE_Q + 4 * sets.ubn + 1;  // full tiles + one partial tile per tile group
     sets.W = dims[0]; sets.H = dims[1];
     {  // a bin of binsize px meets at most ceil(binsize/block)+1 NMS blocks per axis, one feature per class each
       const int32_t blk = g.scale * (g.n + 1);

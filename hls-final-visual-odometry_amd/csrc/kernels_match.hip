@@ -32,6 +32,20 @@
 #define VH_FLOW_LDS_PAD_DEFAULT 18000
 #endif
 
+#ifdef VH_FLOW_STATS
+// debug build only (EXTRA=-DVH_FLOW_STATS): what the flow search executed --
+// [0] tiles [1] chunks [2..4] trips without test / v test / full test [5] queries [6] columns [7] queries searched again
+__device__ unsigned long long g_flow_stats[8];
+extern "C" int32_t vh_debug_flow_stats(unsigned long long *out, int32_t reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_stats), sizeof(g_flow_stats)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_flow_stats), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+#define VH_STAT(k, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_flow_stats[k], (unsigned long long)(n)); } while (0)
+#else
+#define VH_STAT(k, n) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ int32_t wave_min(int32_t v) {
@@ -56,21 +70,107 @@ __device__ __forceinline__ uint32_t sad4hi(uint32_t a, uint32_t b, uint32_t acc)
   return __builtin_amdgcn_sad_hi_u8(a, b, acc);  // v_sad_hi_u8: the same sum added at bit 16 of acc
 }
 
-// One tile of the flow search: Q queries per lane (Q*64 consecutive bin-ordered
-// queries per wave); every candidate record is read from LDS once per wave and
-// used for Q queries.  At Q = 1 the broadcast reads (2.25 ds_read_b128 per
-// candidate and wave, 4 LDS cycles each, four SIMDs sharing one LDS array) keep
-// the LDS ~85 % busy beside the 8 v_sad_u8 per candidate; Q = 2 halves that --
-// and was measured 15 % SLOWER on MI355X (flow search alone, S = 128: 1180 vs
-// 1028 us): the kernel is bound by VALU issue, not by the LDS, and a 128-query
-// tile spans more bin columns, so that its lanes evaluate ~10 % more candidates
-// outside their own windows and fewer columns take the cheap accept tests.
-// VH_FLOW_Q (vh_dev.h) therefore stays 1.
-template <int Q, bool HI>
+// All-reduce over each 16-lane row of the wave with DPP row rotations (no LDS, no
+// bpermute): afterwards every lane holds the extremum of its row.
+template <bool MAX>
+__device__ __forceinline__ int32_t row16_allreduce(int32_t v) {
+#define VH_ROW_STEP(CTRL)                                                                   \
+  {                                                                                         \
+    const int32_t t = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);             \
+    v = MAX ? max(v, t) : min(v, t);                                                        \
+  }
+  VH_ROW_STEP(0x128)  // row_ror:8
+  VH_ROW_STEP(0x124)  // row_ror:4
+  VH_ROW_STEP(0x122)  // row_ror:2
+  VH_ROW_STEP(0x121)  // row_ror:1
+#undef VH_ROW_STEP
+  return v;
+}
+
+// findMatch for ONE query by the whole wave (lanes over candidates): the slow,
+// literal path behind the speculative search below.  Walks the query's own bin
+// range (matcher.cpp:237-246), applies the accept test (matcher.cpp:249) and
+// keeps min (SAD << 19 | position - pbase): the reference's first strict minimum.
+// Returns the key, 0xFFFFFFFF when no candidate is inside the window.
+__device__ __forceinline__ uint32_t flow_query_by_wave(const VhSets &s, int32_t radius, int32_t rv, int32_t c, int32_t pbase,
+                                                       const int32_t *__restrict__ cbs, const uint32_t *__restrict__ cuv,
+                                                       const uint4 *__restrict__ cdesc, int32_t u1, int32_t v1,
+                                                       const uint32_t (&qd)[8]) {
+  const int32_t lane = threadIdx.x & 63;
+  const auto bin_of = [&](int32_t x, int32_t nb) -> int32_t { return min(max(x, 0) / s.binsize, nb - 1); };
+  const int32_t ub0 = bin_of(u1 - radius, s.ubn), ub1 = bin_of(u1 + radius, s.ubn);
+  const int32_t vb0 = bin_of(v1 - rv, s.vbn), vb1 = bin_of(v1 + rv, s.vbn);
+  const us2 lo2 = {(unsigned short)(u1 - radius), (unsigned short)(v1 - rv)};
+  const us2 span2 = {(unsigned short)(2 * radius), (unsigned short)(2 * rv)};
+  uint32_t k = 0xFFFFFFFFu;
+  for (int32_t ub = ub0; ub <= ub1; ub++) {
+    const int32_t row = (c * s.ubn + ub) * s.vbn;
+    const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + vb0]);
+    const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + vb1 + 1]);
+    for (int32_t p = p0 + lane; p < p1; p += 64) {
+      const us2 t = as_us2(cuv[p]) - lo2;
+      const us2 m = __builtin_elementwise_min(t, span2);
+      if (as_u32(t) != as_u32(m)) continue;
+      const uint4 b0 = cdesc[2 * (int64_t)p], b1 = cdesc[2 * (int64_t)p + 1];
+      uint32_t sad = sad4(qd[0], b0.x, 0);
+      sad = sad4(qd[1], b0.y, sad); sad = sad4(qd[2], b0.z, sad); sad = sad4(qd[3], b0.w, sad);
+      sad = sad4(qd[4], b1.x, sad); sad = sad4(qd[5], b1.y, sad); sad = sad4(qd[6], b1.z, sad); sad = sad4(qd[7], b1.w, sad);
+      k = min(k, (sad << 19) | (uint32_t)(p - pbase));
+    }
+  }
+#pragma unroll
+  for (int32_t d = 32; d >= 1; d >>= 1) k = min(k, (uint32_t)__shfl_xor((int32_t)k, d));
+  return k;
+}
+
+// One tile of the flow search.
+//
+// A tile is T = 64*Q/P consecutive bin-ordered queries of one class.  The wave's
+// 64 lanes are P *phases* of L = 64/P lanes; lane (phase, l) holds the Q queries
+// l, l+L, .. of the tile, so every phase holds the whole tile, and the P phases
+// take the candidates j, j+1, .., j+P-1 of the staged chunk in the same step:
+// one candidate stream shared by all phases, each candidate evaluated by exactly
+// one phase.  Compared with one query per lane and a wave-uniform candidate
+// (round 1: T = 64, P = 1, Q = 1):
+//  * a 16- or 32-query tile is compact (about one 50x50 bin), so the union of its
+//    lanes' windows exceeds each lane's own window by less: fewer evaluated pairs
+//    outside the window (tools/tile_model2.py, tools/flow_stats.py);
+//  * with Q = 2 every candidate record read from LDS serves two queries per
+//    lane.  The record reads (4 LDS cycles per ds_read_b128 and wave, four SIMDs
+//    sharing one LDS array) otherwise saturate the LDS beside 8 v_sad_u8 per
+//    step: profiles/r02_ubench_valu.txt, last block.
+// The minimum over a query's candidates is split over the P phases and joined
+// with log2(P) shuffles per tile.
+//
+// SPEC (the default): *speculative* search.  The per-pair accept test of
+// matcher.cpp:249 is not applied in the loop at all: every lane takes the minimum
+// key over the whole union region the wave walks -- a superset of its own window
+// -- which costs 8 v_sad_hi_u8 + 1.25 other VALU instructions per pair instead of
+// 8 + 3.5..5.25 (the tests were 29 % of the loop's instructions, more than the
+// pairs evaluated outside the window).  At the end each lane tests ONE candidate,
+// its winner: if it lies inside the lane's window it is also the minimum over the
+// window (keys are unique), i.e. exactly findMatch's result.  Otherwise (some
+// out-of-window candidate resembled the query more than every in-window one:
+// 0.5 % of the queries on the benchmark frames, ~10 % with two grey levels of
+// sensor noise added, where most features have no true partner) the query is
+// searched again by the whole wave with the literal test (flow_query_by_wave).
+// Results are identical either way; only the time depends on the data.
+// !SPEC keeps the tested loop: three accept-test classes per bin as in round 1.
+//
+// Staged chunk: 64 candidates, lane j loads candidate min(pc+j, p1-1).  Slots
+// past the end of the column therefore hold copies of its last candidate; they
+// are evaluated like real ones with positions p1, p1+1, ..: same SAD as the
+// original at a larger position, so their keys are larger than the original's
+// key and never change a minimum.  That lets every range of the chunk be rounded
+// outward to whole trips of 2*P candidates without any tail code.
+template <int Q, int P, bool HI, bool SPEC>
 __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream,
                                           int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c,
                                           int32_t pbase, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
-  const int32_t lane = threadIdx.x & 63;
+  constexpr int L = 64 / P;
+  static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile (row-wise window reduction)");
+  constexpr int TRIP = 2 * P;  // candidates per trip: two steps, joined by one v_min3_u32 per query
+  const int32_t lane = threadIdx.x & 63, ph = lane / L, l = lane % L;
   const uint32_t *__restrict__ quv = s.s_uv + (int64_t)qset * s.cap;
   const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
   const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
@@ -82,63 +182,62 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
 
   bool valid[Q];
   uint4 a0[Q], a1[Q];
+  uint32_t uv1[Q];
   int32_t v_lo[Q];
   us2 lo2[Q];
   uint32_t best_key[Q];
-  int32_t ub_lo = 0x7FFFFFFF, vb_lo = 0x7FFFFFFF, ub_hi = -1, vb_hi = -1;
-  int32_t ulo_max = -0x40000000, uhi_min = 0x40000000, vlo_max = -0x40000000, vhi_min = 0x40000000;
+  int32_t umin = 0x7FFFFFFF, umax = -1, vmin = 0x7FFFFFFF, vmax = -1;
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
-    const int32_t q = q0 + 64 * qi + lane;
+    const int32_t q = q0 + L * qi + l;
     valid[qi] = q < q1;
     const int32_t ql = valid[qi] ? q : q0;
-    const uint32_t uv1 = quv[ql];
+    uv1[qi] = quv[ql];
     a0[qi] = qdesc[2 * (int64_t)ql]; a1[qi] = qdesc[2 * (int64_t)ql + 1];
-    const int32_t u1 = uv1 & 0xFFFF, v1 = uv1 >> 16;
-    // search window (matcher.cpp:231-234; stereo: v narrowed to +-disp_tolerance)
-    const int32_t u_lo = u1 - a.radius, u_hi = u1 + a.radius, v_hi = v1 + rv;
-    v_lo[qi] = v1 - rv;
+    const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
+    // search window (matcher.cpp:231-234; stereo: v narrowed to +-disp_tolerance).
     // Accept test of matcher.cpp:249 in packed 16-bit arithmetic: with
     // t = (u2,v2) - (u_lo,v_lo) (mod 2^16 per half), the candidate is inside the
     // window iff t.u <= 2*radius and t.v <= 2*rv, i.e. iff min(t, span) == t.
     // Exact because coordinates are < 2^14 and radii <= 2^14 (|u2-u1|+r < 2^15).
-    lo2[qi] = us2{(unsigned short)u_lo, (unsigned short)v_lo[qi]};
+    v_lo[qi] = v1 - rv;
+    lo2[qi] = us2{(unsigned short)(u1 - a.radius), (unsigned short)v_lo[qi]};
     best_key[qi] = 0xFFFFFFFFu;
-    if (valid[qi]) {
-      // bins of interest (matcher.cpp:237-240); for x<0 the clamp to 0 makes the
-      // truncating division equivalent to the reference's floor
-      ub_lo = min(ub_lo, min(max(u_lo, 0) / s.binsize, s.ubn - 1));
-      ub_hi = max(ub_hi, min(max(u_hi, 0) / s.binsize, s.ubn - 1));
-      vb_lo = min(vb_lo, min(max(v_lo[qi], 0) / s.binsize, s.vbn - 1));
-      vb_hi = max(vb_hi, min(max(v_hi, 0) / s.binsize, s.vbn - 1));
-      ulo_max = max(ulo_max, u_lo); uhi_min = min(uhi_min, u_hi);
-      vlo_max = max(vlo_max, v_lo[qi]); vhi_min = min(vhi_min, v_hi);
-    }
+    // (lanes past q1 repeat query q0: it is valid, so the extrema are unchanged)
+    umin = min(umin, u1); umax = max(umax, u1); vmin = min(vmin, v1); vmax = max(vmax, v1);
   }
-  const int32_t UB0 = __builtin_amdgcn_readfirstlane(wave_min(ub_lo));
-  const int32_t UB1 = __builtin_amdgcn_readfirstlane(wave_max(ub_hi));
-  const int32_t VB0 = __builtin_amdgcn_readfirstlane(wave_min(vb_lo));
-  const int32_t VB1 = __builtin_amdgcn_readfirstlane(wave_max(vb_hi));
+  // every 16-lane row holds all queries of the tile: row-wise extrema are the tile's
+  umin = __builtin_amdgcn_readfirstlane(row16_allreduce<false>(umin));
+  umax = __builtin_amdgcn_readfirstlane(row16_allreduce<true>(umax));
+  vmin = __builtin_amdgcn_readfirstlane(row16_allreduce<false>(vmin));
+  vmax = __builtin_amdgcn_readfirstlane(row16_allreduce<true>(vmax));
+  // bins of interest of the union window (matcher.cpp:237-240; for x<0 the clamp to 0
+  // makes the truncating division equivalent to the reference's floor); the bin of a
+  // coordinate is monotone, so the union's bins follow from the extreme queries
+  const auto bin_of = [&](int32_t x, int32_t nb) -> int32_t {
+    const uint32_t xx = (uint32_t)max(x, 0);
+    return min((int32_t)(s.binsize == 1 ? xx : __umulhi(xx, s.inv_binsize)), nb - 1);
+  };
+  const int32_t UB0 = bin_of(umin - a.radius, s.ubn), UB1 = bin_of(umax + a.radius, s.ubn);
+  const int32_t VB0 = bin_of(vmin - rv, s.vbn), VB1 = bin_of(vmax + rv, s.vbn);
   const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * rv)};
-  // columns whose pixel range [ub*bs, ub*bs+bs-1] is inside EVERY query's u window
-  const int32_t ULO_MAX = __builtin_amdgcn_readfirstlane(wave_max(ulo_max));
-  const int32_t UHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(uhi_min));
-  // v-bins [VA0, VA1] whose pixel rows lie inside EVERY query's v window: in an
-  // interior column their candidates need no accept test at all
-  const int32_t VLO_MAX = __builtin_amdgcn_readfirstlane(wave_max(vlo_max));
-  const int32_t VHI_MIN = __builtin_amdgcn_readfirstlane(wave_min(vhi_min));
-  const int32_t VA0 = max(VB0, (max(VLO_MAX, 0) + s.binsize - 1) / s.binsize);
-  const int32_t VA1 = min(VB1, (VHI_MIN + 1) / s.binsize - 1);
+  // (tested loop) columns whose pixel range [ub*bs, ub*bs+bs-1] is inside EVERY query's u
+  // window, and v-bins [VA0, VA1] whose pixel rows lie inside EVERY query's v window: in
+  // an interior column their candidates need no accept test at all
+  const int32_t ULO_MAX = umax - a.radius, UHI_MIN = umin + a.radius;
+  const int32_t VLO_MAX = vmax - rv, VHI_MIN = vmin + rv;
+  const int32_t VA0 = SPEC ? 0 : max(VB0, (max(VLO_MAX, 0) + s.binsize - 1) / s.binsize);
+  const int32_t VA1 = SPEC ? 0 : min(VB1, (VHI_MIN + 1) / s.binsize - 1);
 
-  // best = min over accepted candidates of (SAD << 19 | position): positions in
-  // bin order are the reference's visiting order, so this key reproduces its
-  // strict-< first-minimum rule (matcher.cpp:264).  SAD <= 8160 < 2^13.
-  // HI: when the positions this tile can visit span less than 2^16, the key is
-  // (SAD << 16 | position - pbase) instead and costs nothing to build: the SAD
-  // chain runs on v_sad_hi_u8, which accumulates at bit 16, seeded with the
-  // relative position in the low half.
-  // TEST: 2 = full (u,v) window test, 1 = v only, 0 = none (see the column loop)
-  auto make_key = [&](auto test, int32_t qi, uint32_t uv2, const uint4 &b0, const uint4 &b1, int32_t p) -> uint32_t {
+  // best = min over candidates of (SAD << 16 | position - pbase), pbase = first
+  // position of the class: positions in bin order are the reference's visiting
+  // order, so this key reproduces its strict-< first-minimum rule (matcher.cpp:264).
+  // HI: the key comes straight out of a v_sad_hi_u8 chain (it accumulates at bit 16)
+  // seeded with the relative position; needs < 2^16 positions per class.  Otherwise
+  // (SAD << 19 | position - pbase) from a v_sad_u8 chain and one v_lshl_or_b32
+  // (SAD <= 8160 < 2^13, < 2^19 positions per class).
+  // TEST: 2 = full (u,v) window test, 1 = v only, 0 = none
+  auto make_key = [&](auto test, int32_t qi, uint32_t uv2, const uint4 &b0, const uint4 &b1, uint32_t seed) -> uint32_t {
     constexpr int TEST = decltype(test)::value;
     bool out = false;
     if (TEST == 2) {
@@ -150,7 +249,7 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
     }
     uint32_t key;
     if (HI) {
-      key = sad4hi(a0[qi].x, b0.x, (uint32_t)(p - pbase));
+      key = sad4hi(a0[qi].x, b0.x, seed);
       key = sad4hi(a0[qi].y, b0.y, key);
       key = sad4hi(a0[qi].z, b0.z, key);
       key = sad4hi(a0[qi].w, b0.w, key);
@@ -167,91 +266,159 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
       sad = sad4(a1[qi].y, b1.y, sad);
       sad = sad4(a1[qi].z, b1.z, sad);
       sad = sad4(a1[qi].w, b1.w, sad);
-      key = (sad << 19) | (uint32_t)p;
+      key = (sad << 19) | seed;
     }
     return (TEST != 0 && out) ? 0xFFFFFFFFu : key;
   };
-  // Candidate stream through a wave-private LDS chunk: lane j of the wave fetches
-  // candidate p+j (coalesced 36 B per lane), the chunk is then consumed with
-  // broadcast reads so that v_sad_u8 runs on VGPR operands (its SGPR-operand form
-  // issues ~13 % slower, tools/ubench_valu.hip) and no scalar-load round trips
-  // sit in the loop.  The next chunk's global loads are in flight while the
-  // current one is consumed.
-  for (int32_t ub = UB0; ub <= UB1; ub++) {
-    const int32_t row = (c * s.ubn + ub) * s.vbn;
-    const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + VB0]);
-    const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + VB1 + 1]);
-    const bool interior = ub * s.binsize >= ULO_MAX && ub * s.binsize + s.binsize - 1 <= UHI_MIN;
-    // positions of the untested v-bins of this column (empty when VA0 > VA1)
-    const int32_t pa0 = (interior && VA0 <= VA1) ? __builtin_amdgcn_readfirstlane(cbs[row + VA0]) : p1;
-    const int32_t pa1 = (interior && VA0 <= VA1) ? __builtin_amdgcn_readfirstlane(cbs[row + VA1 + 1]) : p1;
-    for (int32_t pc = p0; pc < p1; pc += 64) {
-      const int32_t mcnt = min(64, p1 - pc);
-      const int32_t pl = min(pc + lane, p1 - 1);
-      const uint32_t gu = cuv[pl];
-      const uint4 g0 = cdesc[2 * (int64_t)pl], g1 = cdesc[2 * (int64_t)pl + 1];
+  VH_STAT(0, 1); VH_STAT(5, q1 - q0); VH_STAT(6, UB1 - UB0 + 1);
+  // The walk, software-pipelined over chunks: the column table (first/last position of
+  // the bins [VB0, VB1] of up to 64 columns, one column per lane) is fetched with one
+  // round trip per tile, and the records of chunk k+1 are in flight while chunk k is
+  // consumed.  With 16..32 queries per tile a chunk is only a few hundred cycles of
+  // work, less than one L2 round trip; unpipelined, those round trips (two per column
+  // for the table, one per chunk for the records) bounded small tiles.
+  for (int32_t cb = UB0; cb <= UB1; cb += 64) {
+    const int32_t ncb = min(64, UB1 - cb + 1);
+    int32_t t_p0 = 0, t_p1 = 0, t_a0 = 0, t_a1 = 0;
+    if (lane < ncb) {
+      const int32_t row = (c * s.ubn + cb + lane) * s.vbn;
+      t_p0 = cbs[row + VB0]; t_p1 = cbs[row + VB1 + 1];
+      if (!SPEC) {
+        const int32_t ubx = cb + lane;
+        const bool in_ = ubx * s.binsize >= ULO_MAX && ubx * s.binsize + s.binsize - 1 <= UHI_MIN;
+        // t_a0 > t_a1 marks an edge column (full test); an interior one without untested bins has t_a0 == t_a1 == t_p1
+        t_a0 = in_ ? ((VA0 <= VA1) ? cbs[row + VA0] : t_p1) : 1;
+        t_a1 = in_ ? ((VA0 <= VA1) ? cbs[row + VA1 + 1] : t_p1) : 0;
+      }
+    }
+    // chunk cursor: column ci of the batch, positions [pc, p1)
+    int32_t ci = -1, pc = 0, p1 = 0;
+    const auto advance = [&]() -> bool {  // to the next non-empty chunk; false past the last one (wave-uniform)
+      pc += 64;
+      while (pc >= p1) {
+        if (++ci >= ncb) return false;
+        pc = __builtin_amdgcn_readlane(t_p0, ci); p1 = __builtin_amdgcn_readlane(t_p1, ci);
+      }
+      return true;
+    };
+    pc = -64;
+    if (!advance()) continue;
+    int32_t pl = min(pc + lane, p1 - 1);
+    uint32_t gu = 0;
+    if (!SPEC) gu = cuv[pl];
+    uint4 g0 = cdesc[2 * (int64_t)pl], g1 = cdesc[2 * (int64_t)pl + 1];
+    for (;;) {
+      VH_STAT(1, 1);
+      const int32_t c_pc = pc, c_p1 = p1, c_ci = ci;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
-      wU[lane] = gu; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
+      wD[lane] = g0; wD[64 + lane] = g1;
+      if (!SPEC) wU[lane] = gu;
+      const bool more = advance();
+      if (more) {  // next chunk's records: in flight during the trips below
+        pl = min(pc + lane, p1 - 1);
+        if (!SPEC) gu = cuv[pl];
+        g0 = cdesc[2 * (int64_t)pl]; g1 = cdesc[2 * (int64_t)pl + 1];
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
+      const int32_t mcnt = min(64, c_p1 - c_pc);
+      const int32_t jend = (mcnt + TRIP - 1) & ~(TRIP - 1);  // <= 64: trailing slots hold copies of the last candidate
+      const uint4 *rd = wD + ph;                              // this phase's slot of step 0 (second half: +64)
+      const uint32_t *ru = wU + ph;
+      uint32_t seedA = (uint32_t)(c_pc - pbase + ph), seedB = seedA + P;
       int32_t j = 0;
-      // CPI candidates per trip, two per update: min(best, kA, kB) is one v_min3_u32
-      constexpr int CPI = Q == 1 ? 4 : 2;
-      auto run = [&](auto test, int32_t jend) {
-        for (; j + CPI <= jend; j += CPI) {
+      auto run = [&](auto test, int32_t jstop) {
+        if (jstop > j) VH_STAT(2 + decltype(test)::value, (jstop - j) / TRIP);
+        for (; j < jstop; j += TRIP) {
+          const uint4 dA0 = rd[0], dA1 = rd[64], dB0 = rd[P], dB1 = rd[64 + P];
+          uint32_t uA = 0, uB = 0;
+          if (decltype(test)::value != 0) { uA = ru[0]; uB = ru[P]; }
 #pragma unroll
-          for (int32_t k = 0; k < CPI; k += 2) {
-            const uint32_t uA = wU[j + k], uB = wU[j + k + 1];
-            const uint4 dA0 = wD[2 * (j + k)], dA1 = wD[2 * (j + k) + 1], dB0 = wD[2 * (j + k) + 2], dB1 = wD[2 * (j + k) + 3];
-#pragma unroll
-            for (int32_t qi = 0; qi < Q; qi++) {
-              const uint32_t kA = make_key(test, qi, uA, dA0, dA1, pc + j + k), kB = make_key(test, qi, uB, dB0, dB1, pc + j + k + 1);
-              best_key[qi] = min(min(kA, kB), best_key[qi]);
-            }
+          for (int32_t qi = 0; qi < Q; qi++) {
+            const uint32_t kA = make_key(test, qi, uA, dA0, dA1, seedA), kB = make_key(test, qi, uB, dB0, dB1, seedB);
+            best_key[qi] = min(min(kA, kB), best_key[qi]);
           }
-        }
-        for (; j < jend; j++) {
-          const uint32_t uA = wU[j];
-          const uint4 dA0 = wD[2 * j], dA1 = wD[2 * j + 1];
-#pragma unroll
-          for (int32_t qi = 0; qi < Q; qi++) best_key[qi] = min(best_key[qi], make_key(test, qi, uA, dA0, dA1, pc + j));
+          rd += TRIP; ru += TRIP; seedA += TRIP; seedB += TRIP;
         }
       };
-      if (interior) {
-        // [0, ja): v test, [ja, jb): no test, [jb, mcnt): v test
-        // (the untested range is shrunk inward to multiples of the unroll factor:
-        // testing a few candidates that would not need it is always valid, and only
-        // the chunk's tail is then left to the one-candidate loop)
-        const int32_t ja = min((min(max(pa0 - pc, 0), mcnt) + CPI - 1) & ~(CPI - 1), mcnt);
-        const int32_t jb = max(min(max(pa1 - pc, 0), mcnt) & ~(CPI - 1), ja);
-        run(std::integral_constant<int, 1>{}, ja);
-        run(std::integral_constant<int, 0>{}, jb);
-        run(std::integral_constant<int, 1>{}, mcnt);
+      if (SPEC) {
+        run(std::integral_constant<int, 0>{}, jend);
       } else {
-        run(std::integral_constant<int, 2>{}, mcnt);
+        const int32_t pa0 = __builtin_amdgcn_readlane(t_a0, c_ci), pa1 = __builtin_amdgcn_readlane(t_a1, c_ci);
+        if (pa0 <= pa1) {
+          // interior column.  [0, ja): v test, [ja, jb): no test, [jb, jend): v test -- the
+          // untested range shrunk inward to whole trips (testing a candidate that would
+          // not need it is always valid)
+          const int32_t ja = min((min(max(pa0 - c_pc, 0), mcnt) + TRIP - 1) & ~(TRIP - 1), jend);
+          const int32_t jb = max(min(max(pa1 - c_pc, 0), mcnt) & ~(TRIP - 1), ja);
+          run(std::integral_constant<int, 1>{}, ja);
+          run(std::integral_constant<int, 0>{}, jb);
+          run(std::integral_constant<int, 1>{}, jend);
+        } else {
+          run(std::integral_constant<int, 2>{}, jend);
+        }
+      }
+      if (!more) break;
+    }
+  }
+  uint32_t kfin[Q];
+  bool redo[Q];
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    // join the phases: lanes l, l+L, l+2L, .. hold partial minima of the same query
+    uint32_t k = best_key[qi];
+#pragma unroll
+    for (int32_t d = L; d < 64; d <<= 1) k = min(k, (uint32_t)__shfl_xor((int32_t)k, d));
+    // wide form from here on: SAD << 19 | relative position
+    if (HI && k != 0xFFFFFFFFu) k = ((k >> 16) << 19) | (k & 0xFFFFu);
+    kfin[qi] = k;
+    redo[qi] = false;
+    if (SPEC && valid[qi] && ph == 0 && k != 0xFFFFFFFFu) {
+      // the winner over the union region: inside this query's own window?
+      const us2 t = as_us2(cuv[pbase + (int32_t)(k & 0x7FFFFu)]) - lo2[qi];
+      const us2 m = __builtin_elementwise_min(t, span2);
+      redo[qi] = as_u32(t) != as_u32(m);
+    }
+  }
+  if (SPEC) {
+#pragma unroll
+    for (int32_t qi = 0; qi < Q; qi++) {
+      uint64_t todo = __ballot(redo[qi]);
+      if (todo) VH_STAT(7, __popcll(todo));
+      while (todo) {  // wave-uniform
+        const int32_t fl = (int32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint32_t qd[8];
+        qd[0] = __builtin_amdgcn_readlane(a0[qi].x, fl); qd[1] = __builtin_amdgcn_readlane(a0[qi].y, fl);
+        qd[2] = __builtin_amdgcn_readlane(a0[qi].z, fl); qd[3] = __builtin_amdgcn_readlane(a0[qi].w, fl);
+        qd[4] = __builtin_amdgcn_readlane(a1[qi].x, fl); qd[5] = __builtin_amdgcn_readlane(a1[qi].y, fl);
+        qd[6] = __builtin_amdgcn_readlane(a1[qi].z, fl); qd[7] = __builtin_amdgcn_readlane(a1[qi].w, fl);
+        const uint32_t quv1 = __builtin_amdgcn_readlane(uv1[qi], fl);
+        const uint32_t k = flow_query_by_wave(s, a.radius, rv, c, pbase, cbs, cuv, cdesc, (int32_t)(quv1 & 0xFFFF), (int32_t)(quv1 >> 16), qd);
+        if (lane == fl) kfin[qi] = k;
       }
     }
   }
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
-    if (valid[qi]) {
+    if (valid[qi] && ph == 0) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t bp = HI ? pbase + (int32_t)(best_key[qi] & 0xFFFFu) : (int32_t)(best_key[qi] & 0x7FFFFu);
-      const int32_t r = (best_key[qi] == 0xFFFFFFFFu) ? 0 : cidx[bp];
-      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q0 + 64 * qi + lane]] = r;
+      const int32_t r = (kfin[qi] == 0xFFFFFFFFu) ? 0 : cidx[pbase + (int32_t)(kfin[qi] & 0x7FFFFu)];
+      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q0 + L * qi + l]] = r;
     }
   }
 }
 
+template <bool SPEC>
 __global__ void __launch_bounds__(256)
 match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
-  __shared__ uint4 sDesc[4 * 128];
-  __shared__ uint32_t sUv[4 * 64];
+  __shared__ uint4 sDesc[4 * 128];   // per wave: 64 staged candidates, first | second descriptor half
+  __shared__ uint32_t sUv[4 * 64];   // (tested loop only) their u | v << 16
   const int32_t pass = blockIdx.y, stream = blockIdx.z;
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
   const int32_t ntile = s.tile_cnt[qset];
-  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;   // [64][2] uint4
-  uint32_t *wU = sUv + (threadIdx.x >> 6) * 64;   // [64]
+  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
+  uint32_t *wU = sUv + (threadIdx.x >> 6) * 64;
   for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); tile < ntile;
        tile += gridDim.x * 4) {
     const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
@@ -261,14 +428,9 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
     const int32_t *cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
-    // tiles hold up to VH_TILE_Q = 64 * VH_FLOW_Q queries
-    if (pend - pbase <= 0xFFFF && !a.wide_keys) {
-      if (VH_FLOW_Q > 1 && q1 - q0 > 64) flow_tile<VH_FLOW_Q, true>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
-      else flow_tile<1, true>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
-    } else {
-      if (VH_FLOW_Q > 1 && q1 - q0 > 64) flow_tile<VH_FLOW_Q, false>(s, a, pass, stream, qset, cset, q0, q1, c, 0, wD, wU, best);
-      else flow_tile<1, false>(s, a, pass, stream, qset, cset, q0, q1, c, 0, wD, wU, best);
-    }
+    // (+64: the copies past the end of a column carry positions up to 63 past it)
+    if (pend - pbase + 64 <= 0x10000 && !a.wide_keys) flow_tile<VH_FLOW_Q, VH_FLOW_P, true, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
+    else flow_tile<VH_FLOW_Q, VH_FLOW_P, false, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
   }
 }
 
@@ -661,7 +823,10 @@ void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, 
   // being starved until it ends: +5 % throughput measured (sweep 0..60000 B,
   // VH_FLOW_LDS_PAD overrides).
   static const int pad = [] { const char *e = getenv("VH_FLOW_LDS_PAD"); return e ? atoi(e) : VH_FLOW_LDS_PAD_DEFAULT; }();
-  hipLaunchKernelGGL(match_kernel, grid, dim3(256), (size_t)pad, st, s, fl, best);
+  // VH_FLOW_TESTED=1: the loop with the per-pair accept tests instead of the speculative one (same results)
+  static const int tested = [] { const char *e = getenv("VH_FLOW_TESTED"); return e ? atoi(e) : 0; }();
+  if (tested) hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), (size_t)pad, st, s, fl, best);
+  else hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), (size_t)pad, st, s, fl, best);
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st) {

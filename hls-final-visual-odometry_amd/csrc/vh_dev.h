@@ -34,8 +34,15 @@
 #define VH_MARGIN 7          // src/matcher.cpp:38
 #define VH_CHUNK 1024        // NMS blocks per emit workgroup
 #define VH_WAVE 64
-#define VH_FLOW_Q 1           // queries per lane in the flow search (kernels_match.hip: 2 was measured slower)
-#define VH_TILE_Q (64 * VH_FLOW_Q)  // queries per flow-search tile
+// Flow search (kernels_match.hip): a wave is VH_FLOW_P phases of 64/VH_FLOW_P lanes, VH_FLOW_Q
+// queries per lane; the phases share one candidate stream.
+#ifndef VH_FLOW_Q
+#define VH_FLOW_Q 2
+#endif
+#ifndef VH_FLOW_P
+#define VH_FLOW_P 4
+#endif
+#define VH_TILE_Q (64 * VH_FLOW_Q / VH_FLOW_P)  // queries per flow-search tile
 #define VH_NO_CODE 0xFFFFu
 
 struct VhGeom {
