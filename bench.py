@@ -43,7 +43,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 KERNELS = ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill", "bin_sort",
-           "match_stereo", "match_flow", "chain", "emit_matches")
+           "match", "chain", "emit_matches")
 
 
 def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
@@ -301,7 +301,7 @@ def main():
             # rate tools/ubench_valu.hip measured for that instruction (profiles/r01_ubench_valu.txt:
             # 4.86 SIMD-cycles at the nominal 2.4 GHz, 1024 SIMDs) -- 8 SADs per in-window pair
             valu = None
-            if dom == "match_flow" and nfm.mean() < 20000:  # (the pair count below is O(N^2) host work)
+            if dom == "match" and nfm.mean() < 20000:  # (the pair count below is O(N^2) host work)
                 pairs_ = []
                 for s_ in range(min(S, 3)):
                     f = [grp.getFeatures(s_, w_) for w_ in range(4)]

@@ -437,8 +437,7 @@ struct Group {
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_cur], 0));
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_prev], 0));
     if (ev_post_valid[buf]) VH_HIP(hipStreamWaitEvent(ms, ev_post[buf], 0));
-    { Scope sc(this, "match_stereo", ms); vh_launch_match_stereo(sets, a, d_best2[buf], ms); }
-    { Scope sc(this, "match_flow", ms); vh_launch_match_flow(sets, a, d_best2[buf], ms); }
+    { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], ms); }
     VH_HIP(hipGetLastError());
     VH_HIP(hipEventRecord(ev_tables[buf], ms));
     VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
@@ -1068,8 +1067,7 @@ int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3], 
   if ((rc = gq->load_features(VH_SET_1P, m2, n2))) return rc;
   VhMatchArgs a = gq->match_args(VH_METHOD_FLOW);
   a.npass = 1; a.pass[0] = {VH_SET_1C, VH_SET_1P, flow ? 1 : 0, 0};
-  vh_launch_match_stereo(gq->sets, a, gq->d_best, gq->stream);
-  vh_launch_match_flow(gq->sets, a, gq->d_best, gq->stream);
+  vh_launch_match(gq->sets, a, gq->d_best, gq->stream);
   VH_HIP(hipGetLastError());
   if (n1) VH_HIP(hipMemcpyAsync(best, gq->d_best, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, gq->stream));
   VH_HIP(hipStreamSynchronize(gq->stream));

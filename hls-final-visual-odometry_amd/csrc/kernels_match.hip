@@ -28,17 +28,14 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
-#ifndef VH_FLOW_LDS_PAD_DEFAULT
-#define VH_FLOW_LDS_PAD_DEFAULT 18000
-#endif
 
 #ifdef VH_FLOW_STATS
 // debug build only (EXTRA=-DVH_FLOW_STATS): what the flow search executed --
 // [0] tiles [1] chunks [2..4] trips without test / v test / full test [5] queries [6] columns [7] queries searched again
-__device__ unsigned long long g_flow_stats[8];
+__device__ unsigned long long g_flow_stats[12];  // [8] stereo tiles [9] stereo trips [10] stereo queries searched again [11] stereo queries
 extern "C" int32_t vh_debug_flow_stats(unsigned long long *out, int32_t reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_stats), sizeof(g_flow_stats)) != hipSuccess) return -3;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_flow_stats), z, sizeof(z)) != hipSuccess) return -3; }
+  if (reset) { unsigned long long z[12] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_flow_stats), z, sizeof(z)) != hipSuccess) return -3; }
   return 0;
 }
 #define VH_STAT(k, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_flow_stats[k], (unsigned long long)(n)); } while (0)
@@ -87,37 +84,87 @@ __device__ __forceinline__ int32_t row16_allreduce(int32_t v) {
   return v;
 }
 
-// findMatch for ONE query by the whole wave (lanes over candidates): the slow,
-// literal path behind the speculative search below.  Walks the query's own bin
-// range (matcher.cpp:237-246), applies the accept test (matcher.cpp:249) and
-// keeps min (SAD << 19 | position - pbase): the reference's first strict minimum.
-// Returns the key, 0xFFFFFFFF when no candidate is inside the window.
-__device__ __forceinline__ uint32_t flow_query_by_wave(const VhSets &s, int32_t radius, int32_t rv, int32_t c, int32_t pbase,
-                                                       const int32_t *__restrict__ cbs, const uint32_t *__restrict__ cuv,
-                                                       const uint4 *__restrict__ cdesc, int32_t u1, int32_t v1,
-                                                       const uint32_t (&qd)[8]) {
+// The candidate stream of a tile of the flow search: every candidate of class c in
+// the bins [UB0, UB1] x [VB0, VB1] (u-bin major, as Matcher::findMatch visits them,
+// matcher.cpp:243-246), handed to `consume` in chunks of <= 64 consecutive positions,
+// one record per lane (lane j: candidate min(pc+j, p1-1), so the lanes past the end
+// of a column repeat its last candidate).  Software-pipelined: the column table
+// (first/last position of up to 64 columns, one column per lane) costs one round
+// trip per batch of columns, and the records of chunk k+1 are in flight while
+// `consume` works on chunk k.  With 16..32 queries per tile a chunk is only a few
+// hundred cycles of work, less than one L2 round trip; unpipelined, those round
+// trips (two per column for the table, one per chunk for the records) bounded
+// small tiles.
+//   consume(pc, p1, pa0, pa1, pl, gu, g0, g1): chunk [pc, min(pc+64, p1)) of a column
+//   ending at p1; [pa0, pa1) = its positions inside EVERY query's window (TESTED
+//   only; pa0 > pa1 marks a column that is not inside every query's u window);
+//   pl/gu/g0/g1 = this lane's candidate position, u|v<<16 (NEED_UV only) and descriptor.
+template <bool TESTED, bool NEED_UV, class Consume>
+__device__ __forceinline__ void walk_region(const VhSets &s, const int32_t *__restrict__ cbs, const uint32_t *__restrict__ cuv,
+                                            const uint4 *__restrict__ cdesc, int32_t c, int32_t UB0, int32_t UB1, int32_t VB0,
+                                            int32_t VB1, int32_t ULO_MAX, int32_t UHI_MIN, int32_t VA0, int32_t VA1,
+                                            Consume consume) {
   const int32_t lane = threadIdx.x & 63;
-  const auto bin_of = [&](int32_t x, int32_t nb) -> int32_t { return min(max(x, 0) / s.binsize, nb - 1); };
-  const int32_t ub0 = bin_of(u1 - radius, s.ubn), ub1 = bin_of(u1 + radius, s.ubn);
-  const int32_t vb0 = bin_of(v1 - rv, s.vbn), vb1 = bin_of(v1 + rv, s.vbn);
-  const us2 lo2 = {(unsigned short)(u1 - radius), (unsigned short)(v1 - rv)};
-  const us2 span2 = {(unsigned short)(2 * radius), (unsigned short)(2 * rv)};
-  uint32_t k = 0xFFFFFFFFu;
-  for (int32_t ub = ub0; ub <= ub1; ub++) {
-    const int32_t row = (c * s.ubn + ub) * s.vbn;
-    const int32_t p0 = __builtin_amdgcn_readfirstlane(cbs[row + vb0]);
-    const int32_t p1 = __builtin_amdgcn_readfirstlane(cbs[row + vb1 + 1]);
-    for (int32_t p = p0 + lane; p < p1; p += 64) {
-      const us2 t = as_us2(cuv[p]) - lo2;
-      const us2 m = __builtin_elementwise_min(t, span2);
-      if (as_u32(t) != as_u32(m)) continue;
-      const uint4 b0 = cdesc[2 * (int64_t)p], b1 = cdesc[2 * (int64_t)p + 1];
-      uint32_t sad = sad4(qd[0], b0.x, 0);
-      sad = sad4(qd[1], b0.y, sad); sad = sad4(qd[2], b0.z, sad); sad = sad4(qd[3], b0.w, sad);
-      sad = sad4(qd[4], b1.x, sad); sad = sad4(qd[5], b1.y, sad); sad = sad4(qd[6], b1.z, sad); sad = sad4(qd[7], b1.w, sad);
-      k = min(k, (sad << 19) | (uint32_t)(p - pbase));
+  for (int32_t cb = UB0; cb <= UB1; cb += 64) {
+    const int32_t ncb = min(64, UB1 - cb + 1);
+    int32_t t_p0 = 0, t_p1 = 0, t_a0 = 0, t_a1 = 0;
+    if (lane < ncb) {
+      const int32_t row = (c * s.ubn + cb + lane) * s.vbn;
+      t_p0 = cbs[row + VB0]; t_p1 = cbs[row + VB1 + 1];
+      if (TESTED) {
+        const int32_t ubx = cb + lane;
+        const bool in_ = ubx * s.binsize >= ULO_MAX && ubx * s.binsize + s.binsize - 1 <= UHI_MIN;
+        // an interior column without untested bins has t_a0 == t_a1 == t_p1
+        t_a0 = in_ ? ((VA0 <= VA1) ? cbs[row + VA0] : t_p1) : 1;
+        t_a1 = in_ ? ((VA0 <= VA1) ? cbs[row + VA1 + 1] : t_p1) : 0;
+      }
+    }
+    // chunk cursor: column ci of the batch, positions [pc, p1)
+    int32_t ci = -1, pc = -64, p1 = 0;
+    const auto advance = [&]() -> bool {  // to the next non-empty chunk; false past the last one (wave-uniform)
+      pc += 64;
+      while (pc >= p1) {
+        if (++ci >= ncb) return false;
+        pc = __builtin_amdgcn_readlane(t_p0, ci); p1 = __builtin_amdgcn_readlane(t_p1, ci);
+      }
+      return true;
+    };
+    if (!advance()) continue;
+    int32_t pl = min(pc + lane, p1 - 1);
+    uint32_t gu = 0;
+    if (NEED_UV) gu = cuv[pl];
+    uint4 g0 = cdesc[2 * (int64_t)pl], g1 = cdesc[2 * (int64_t)pl + 1];
+    for (;;) {
+      const int32_t c_pc = pc, c_p1 = p1, c_ci = ci, c_pl = pl;
+      const uint32_t c_gu = gu;
+      const uint4 c_g0 = g0, c_g1 = g1;
+      const bool more = advance();
+      if (more) {  // next chunk's records: in flight while this one is consumed
+        pl = min(pc + lane, p1 - 1);
+        if (NEED_UV) gu = cuv[pl];
+        g0 = cdesc[2 * (int64_t)pl]; g1 = cdesc[2 * (int64_t)pl + 1];
+      }
+      int32_t pa0 = 1, pa1 = 0;
+      if (TESTED) { pa0 = __builtin_amdgcn_readlane(t_a0, c_ci); pa1 = __builtin_amdgcn_readlane(t_a1, c_ci); }
+      consume(c_pc, c_p1, pa0, pa1, c_pl, c_gu, c_g0, c_g1);
+      if (!more) break;
     }
   }
+}
+
+// One candidate (this lane's) against ONE wave-uniform query with the literal accept
+// test of matcher.cpp:249: the key (SAD << 19 | position - pbase), or 0xFFFFFFFF.
+// The slow, exact path behind the speculative searches below (lanes over candidates).
+__device__ __forceinline__ uint32_t tested_key_uniform_query(const uint32_t (&qd)[8], us2 lo2, us2 span2, uint32_t uv2,
+                                                             const uint4 &b0, const uint4 &b1, uint32_t relpos) {
+  const us2 t = as_us2(uv2) - lo2;
+  const us2 m = __builtin_elementwise_min(t, span2);
+  uint32_t sad = sad4(qd[0], b0.x, 0);
+  sad = sad4(qd[1], b0.y, sad); sad = sad4(qd[2], b0.z, sad); sad = sad4(qd[3], b0.w, sad);
+  sad = sad4(qd[4], b1.x, sad); sad = sad4(qd[5], b1.y, sad); sad = sad4(qd[6], b1.z, sad); sad = sad4(qd[7], b1.w, sad);
+  return as_u32(t) != as_u32(m) ? 0xFFFFFFFFu : ((sad << 19) | relpos);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t k) {
 #pragma unroll
   for (int32_t d = 32; d >= 1; d >>= 1) k = min(k, (uint32_t)__shfl_xor((int32_t)k, d));
   return k;
@@ -271,60 +318,18 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
     return (TEST != 0 && out) ? 0xFFFFFFFFu : key;
   };
   VH_STAT(0, 1); VH_STAT(5, q1 - q0); VH_STAT(6, UB1 - UB0 + 1);
-  // The walk, software-pipelined over chunks: the column table (first/last position of
-  // the bins [VB0, VB1] of up to 64 columns, one column per lane) is fetched with one
-  // round trip per tile, and the records of chunk k+1 are in flight while chunk k is
-  // consumed.  With 16..32 queries per tile a chunk is only a few hundred cycles of
-  // work, less than one L2 round trip; unpipelined, those round trips (two per column
-  // for the table, one per chunk for the records) bounded small tiles.
-  for (int32_t cb = UB0; cb <= UB1; cb += 64) {
-    const int32_t ncb = min(64, UB1 - cb + 1);
-    int32_t t_p0 = 0, t_p1 = 0, t_a0 = 0, t_a1 = 0;
-    if (lane < ncb) {
-      const int32_t row = (c * s.ubn + cb + lane) * s.vbn;
-      t_p0 = cbs[row + VB0]; t_p1 = cbs[row + VB1 + 1];
-      if (!SPEC) {
-        const int32_t ubx = cb + lane;
-        const bool in_ = ubx * s.binsize >= ULO_MAX && ubx * s.binsize + s.binsize - 1 <= UHI_MIN;
-        // t_a0 > t_a1 marks an edge column (full test); an interior one without untested bins has t_a0 == t_a1 == t_p1
-        t_a0 = in_ ? ((VA0 <= VA1) ? cbs[row + VA0] : t_p1) : 1;
-        t_a1 = in_ ? ((VA0 <= VA1) ? cbs[row + VA1 + 1] : t_p1) : 0;
-      }
-    }
-    // chunk cursor: column ci of the batch, positions [pc, p1)
-    int32_t ci = -1, pc = 0, p1 = 0;
-    const auto advance = [&]() -> bool {  // to the next non-empty chunk; false past the last one (wave-uniform)
-      pc += 64;
-      while (pc >= p1) {
-        if (++ci >= ncb) return false;
-        pc = __builtin_amdgcn_readlane(t_p0, ci); p1 = __builtin_amdgcn_readlane(t_p1, ci);
-      }
-      return true;
-    };
-    pc = -64;
-    if (!advance()) continue;
-    int32_t pl = min(pc + lane, p1 - 1);
-    uint32_t gu = 0;
-    if (!SPEC) gu = cuv[pl];
-    uint4 g0 = cdesc[2 * (int64_t)pl], g1 = cdesc[2 * (int64_t)pl + 1];
-    for (;;) {
+  walk_region<!SPEC, !SPEC>(s, cbs, cuv, cdesc, c, UB0, UB1, VB0, VB1, ULO_MAX, UHI_MIN, VA0, VA1,
+    [&](int32_t pc, int32_t p1, int32_t pa0, int32_t pa1, int32_t, uint32_t gu, const uint4 &g0, const uint4 &g1) {
       VH_STAT(1, 1);
-      const int32_t c_pc = pc, c_p1 = p1, c_ci = ci;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
       wD[lane] = g0; wD[64 + lane] = g1;
       if (!SPEC) wU[lane] = gu;
-      const bool more = advance();
-      if (more) {  // next chunk's records: in flight during the trips below
-        pl = min(pc + lane, p1 - 1);
-        if (!SPEC) gu = cuv[pl];
-        g0 = cdesc[2 * (int64_t)pl]; g1 = cdesc[2 * (int64_t)pl + 1];
-      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
-      const int32_t mcnt = min(64, c_p1 - c_pc);
+      const int32_t mcnt = min(64, p1 - pc);
       const int32_t jend = (mcnt + TRIP - 1) & ~(TRIP - 1);  // <= 64: trailing slots hold copies of the last candidate
       const uint4 *rd = wD + ph;                              // this phase's slot of step 0 (second half: +64)
       const uint32_t *ru = wU + ph;
-      uint32_t seedA = (uint32_t)(c_pc - pbase + ph), seedB = seedA + P;
+      uint32_t seedA = (uint32_t)(pc - pbase + ph), seedB = seedA + P;
       int32_t j = 0;
       auto run = [&](auto test, int32_t jstop) {
         if (jstop > j) VH_STAT(2 + decltype(test)::value, (jstop - j) / TRIP);
@@ -342,24 +347,19 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
       };
       if (SPEC) {
         run(std::integral_constant<int, 0>{}, jend);
+      } else if (pa0 <= pa1) {
+        // interior column.  [0, ja): v test, [ja, jb): no test, [jb, jend): v test -- the
+        // untested range shrunk inward to whole trips (testing a candidate that would
+        // not need it is always valid)
+        const int32_t ja = min((min(max(pa0 - pc, 0), mcnt) + TRIP - 1) & ~(TRIP - 1), jend);
+        const int32_t jb = max(min(max(pa1 - pc, 0), mcnt) & ~(TRIP - 1), ja);
+        run(std::integral_constant<int, 1>{}, ja);
+        run(std::integral_constant<int, 0>{}, jb);
+        run(std::integral_constant<int, 1>{}, jend);
       } else {
-        const int32_t pa0 = __builtin_amdgcn_readlane(t_a0, c_ci), pa1 = __builtin_amdgcn_readlane(t_a1, c_ci);
-        if (pa0 <= pa1) {
-          // interior column.  [0, ja): v test, [ja, jb): no test, [jb, jend): v test -- the
-          // untested range shrunk inward to whole trips (testing a candidate that would
-          // not need it is always valid)
-          const int32_t ja = min((min(max(pa0 - c_pc, 0), mcnt) + TRIP - 1) & ~(TRIP - 1), jend);
-          const int32_t jb = max(min(max(pa1 - c_pc, 0), mcnt) & ~(TRIP - 1), ja);
-          run(std::integral_constant<int, 1>{}, ja);
-          run(std::integral_constant<int, 0>{}, jb);
-          run(std::integral_constant<int, 1>{}, jend);
-        } else {
-          run(std::integral_constant<int, 2>{}, jend);
-        }
+        run(std::integral_constant<int, 2>{}, jend);
       }
-      if (!more) break;
-    }
-  }
+    });
   uint32_t kfin[Q];
   bool redo[Q];
 #pragma unroll
@@ -392,8 +392,18 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
         qd[2] = __builtin_amdgcn_readlane(a0[qi].z, fl); qd[3] = __builtin_amdgcn_readlane(a0[qi].w, fl);
         qd[4] = __builtin_amdgcn_readlane(a1[qi].x, fl); qd[5] = __builtin_amdgcn_readlane(a1[qi].y, fl);
         qd[6] = __builtin_amdgcn_readlane(a1[qi].z, fl); qd[7] = __builtin_amdgcn_readlane(a1[qi].w, fl);
+        // the literal search for this one query by the whole wave, lanes over candidates,
+        // over the query's own bin range (matcher.cpp:237-249)
         const uint32_t quv1 = __builtin_amdgcn_readlane(uv1[qi], fl);
-        const uint32_t k = flow_query_by_wave(s, a.radius, rv, c, pbase, cbs, cuv, cdesc, (int32_t)(quv1 & 0xFFFF), (int32_t)(quv1 >> 16), qd);
+        const int32_t u1 = (int32_t)(quv1 & 0xFFFF), v1 = (int32_t)(quv1 >> 16);
+        const us2 qlo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - rv)};
+        uint32_t k = 0xFFFFFFFFu;
+        walk_region<false, true>(s, cbs, cuv, cdesc, c, bin_of(u1 - a.radius, s.ubn), bin_of(u1 + a.radius, s.ubn),
+                                 bin_of(v1 - rv, s.vbn), bin_of(v1 + rv, s.vbn), 0, 0, 0, 0,
+          [&](int32_t, int32_t, int32_t, int32_t, int32_t pl, uint32_t gu, const uint4 &g0, const uint4 &g1) {
+            k = min(k, tested_key_uniform_query(qd, qlo2, span2, gu, g0, g1, (uint32_t)(pl - pbase)));
+          });
+        k = wave_min_u32(k);
         if (lane == fl) kfin[qi] = k;
       }
     }
@@ -409,16 +419,9 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
 }
 
 template <bool SPEC>
-__global__ void __launch_bounds__(256)
-match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
-  __shared__ uint4 sDesc[4 * 128];   // per wave: 64 staged candidates, first | second descriptor half
-  __shared__ uint32_t sUv[4 * 64];   // (tested loop only) their u | v << 16
-  const int32_t pass = blockIdx.y, stream = blockIdx.z;
-  const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
-  const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
+__device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
+                                          int32_t cset, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
   const int32_t ntile = s.tile_cnt[qset];
-  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
-  uint32_t *wU = sUv + (threadIdx.x >> 6) * 64;
   for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); tile < ntile;
        tile += gridDim.x * 4) {
     const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
@@ -438,23 +441,29 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
 // The 1-d stereo search (v window of +-match_disp_tolerance, stock libviso2;
 // SURVEY App. A.7) accepts only a few dozen candidates per query, all within a
 // handful of image rows, so walking whole 50x50 bins would waste >95 % of the
-// work.  Same lane-per-query / wave-uniform-stream scheme as the flow search,
-// but over the (class, v) ROW index on both sides: a tile is 64 consecutive
-// row-ordered queries of one class (they span only a few rows), and the
-// candidate stream is the single contiguous row range [vmin-tol, vmax+tol] of
-// the candidate set.  The key still carries the candidate's BIN-order position,
-// so the minimum is findMatch's first minimum in (u_bin, v_bin, list) order no
-// matter in which order the rows are walked.
-__global__ void __launch_bounds__(256)
-match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
-  __shared__ uint4 sDesc[4 * 128];
-  __shared__ uint2 sMeta[4 * 64];
-  const int32_t pass = blockIdx.y, stream = blockIdx.z;
-  const int32_t lane = threadIdx.x & 63;
-  const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
-  const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
+// work.  It runs over the (class, v) ROW index on both sides instead: a tile is
+// T = 64*Q/P consecutive row-ordered queries of one class (32 queries span three
+// or four image rows), the candidate stream is the single contiguous row range
+// [vmin-tol, vmax+tol] of the candidate set, shared by P phases of lanes exactly
+// as in the flow search (flow_tile), Q queries per lane.  The search is
+// speculative in the same way: no accept test in the loop (the stream holds every
+// u of those rows, the window only +-match_radius of them), the winner is tested
+// once, and a query whose winner lies outside its window is searched again by the
+// whole wave over its own bins (flow_query_by_wave).  The key carries the
+// candidate's BIN-order position (staged next to its descriptor), so the minimum
+// is findMatch's first minimum in (u_bin, v_bin, list) order no matter in which
+// order the rows are walked.  Round 1 used 64-query tiles with the test in the
+// loop: 100 evaluated candidates and 13 instructions per query and candidate
+// where ~15 candidates are inside the window; this form evaluates ~70 at 9.4.
+template <int Q, int P, bool HI>
+__device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
+                                          int32_t cset, int32_t q0, int32_t q1, int32_t c, int32_t pbase, uint4 *wD,
+                                          uint32_t *wU, int32_t *__restrict__ best) {
+  constexpr int L = 64 / P;
+  static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile");
+  constexpr int TRIP = 2 * P;
+  const int32_t lane = threadIdx.x & 63, ph = lane / L, l = lane % L;
   const int32_t nrow = 4 * s.H;
-  const int32_t *__restrict__ qrs = s.row_start + (int64_t)qset * (nrow + 1);
   const int32_t *__restrict__ crs = s.row_start + (int64_t)cset * (nrow + 1);
   const int32_t *__restrict__ qpos = s.r_pos + (int64_t)qset * s.cap;
   const uint32_t *__restrict__ quv = s.s_uv + (int64_t)qset * s.cap;
@@ -464,103 +473,178 @@ match_rows_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
   const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
   const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
   const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
+  const int32_t *__restrict__ cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
+
+  bool valid[Q];
+  uint4 a0[Q], a1[Q];
+  uint32_t uv1[Q];
+  int32_t qp[Q];
+  uint32_t best_key[Q];
+  int32_t vmin = 0x7FFFFFFF, vmax = -1;
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    const int32_t q = q0 + L * qi + l;
+    valid[qi] = q < q1;
+    qp[qi] = qpos[valid[qi] ? q : q0];  // row order holds bin positions; the records are gathered from the bin-ordered arrays
+    uv1[qi] = quv[qp[qi]];
+    a0[qi] = qdesc[2 * (int64_t)qp[qi]]; a1[qi] = qdesc[2 * (int64_t)qp[qi] + 1];
+    const int32_t v1 = uv1[qi] >> 16;
+    best_key[qi] = 0xFFFFFFFFu;
+    vmin = min(vmin, v1); vmax = max(vmax, v1);
+  }
+  vmin = __builtin_amdgcn_readfirstlane(row16_allreduce<false>(vmin));
+  vmax = __builtin_amdgcn_readfirstlane(row16_allreduce<true>(vmax));
+  VH_STAT(8, 1); VH_STAT(11, q1 - q0);
+  const int32_t VLO = max(vmin - a.disp_tol, 0), VHI = min(vmax + a.disp_tol, s.H - 1);
+  const int32_t r0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VLO]);
+  const int32_t r1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VHI + 1]);
+  auto make_key = [&](int32_t qi, const uint4 &b0, const uint4 &b1, uint32_t seed) -> uint32_t {
+    uint32_t key;
+    if (HI) {
+      key = sad4hi(a0[qi].x, b0.x, seed);
+      key = sad4hi(a0[qi].y, b0.y, key);
+      key = sad4hi(a0[qi].z, b0.z, key);
+      key = sad4hi(a0[qi].w, b0.w, key);
+      key = sad4hi(a1[qi].x, b1.x, key);
+      key = sad4hi(a1[qi].y, b1.y, key);
+      key = sad4hi(a1[qi].z, b1.z, key);
+      key = sad4hi(a1[qi].w, b1.w, key);
+    } else {
+      uint32_t sad = sad4(a0[qi].x, b0.x, 0);
+      sad = sad4(a0[qi].y, b0.y, sad);
+      sad = sad4(a0[qi].z, b0.z, sad);
+      sad = sad4(a0[qi].w, b0.w, sad);
+      sad = sad4(a1[qi].x, b1.x, sad);
+      sad = sad4(a1[qi].y, b1.y, sad);
+      sad = sad4(a1[qi].z, b1.z, sad);
+      sad = sad4(a1[qi].w, b1.w, sad);
+      key = (sad << 19) | seed;
+    }
+    return key;
+  };
+  for (int32_t rc = r0; rc < r1; rc += 64) {
+    const int32_t mcnt = min(64, r1 - rc);
+    const int32_t cp = cpos[min(rc + lane, r1 - 1)];  // slots past the end repeat the last candidate: same key, harmless
+    const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
+    wD[lane] = g0; wD[64 + lane] = g1; wU[lane] = (uint32_t)(cp - pbase);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
+    const int32_t jend = (mcnt + TRIP - 1) & ~(TRIP - 1);
+    VH_STAT(9, jend / TRIP);
+    const uint4 *rd = wD + ph;
+    const uint32_t *ru = wU + ph;
+    for (int32_t j = 0; j < jend; j += TRIP) {
+      const uint4 dA0 = rd[0], dA1 = rd[64], dB0 = rd[P], dB1 = rd[64 + P];
+      const uint32_t sA = ru[0], sB = ru[P];
+#pragma unroll
+      for (int32_t qi = 0; qi < Q; qi++)
+        best_key[qi] = min(min(make_key(qi, dA0, dA1, sA), make_key(qi, dB0, dB1, sB)), best_key[qi]);
+      rd += TRIP; ru += TRIP;
+    }
+  }
+  // join the phases, test the winner against the query's own window, search again where it fails
+  const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * a.disp_tol)};
+  uint32_t kfin[Q];
+  bool redo[Q];
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    uint32_t k = best_key[qi];
+#pragma unroll
+    for (int32_t d = L; d < 64; d <<= 1) k = min(k, (uint32_t)__shfl_xor((int32_t)k, d));
+    if (HI && k != 0xFFFFFFFFu) k = ((k >> 16) << 19) | (k & 0xFFFFu);
+    kfin[qi] = k;
+    redo[qi] = false;
+    if (valid[qi] && ph == 0 && k != 0xFFFFFFFFu) {
+      const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
+      const us2 lo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
+      const us2 t = as_us2(cuv[pbase + (int32_t)(k & 0x7FFFFu)]) - lo2;
+      const us2 m = __builtin_elementwise_min(t, span2);
+      redo[qi] = as_u32(t) != as_u32(m);
+    }
+  }
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    uint64_t todo = __ballot(redo[qi]);
+    if (todo) VH_STAT(10, __popcll(todo));
+    while (todo) {  // wave-uniform
+      const int32_t fl = (int32_t)__builtin_ctzll(todo);
+      todo &= todo - 1;
+      uint32_t qd[8];
+      qd[0] = __builtin_amdgcn_readlane(a0[qi].x, fl); qd[1] = __builtin_amdgcn_readlane(a0[qi].y, fl);
+      qd[2] = __builtin_amdgcn_readlane(a0[qi].z, fl); qd[3] = __builtin_amdgcn_readlane(a0[qi].w, fl);
+      qd[4] = __builtin_amdgcn_readlane(a1[qi].x, fl); qd[5] = __builtin_amdgcn_readlane(a1[qi].y, fl);
+      qd[6] = __builtin_amdgcn_readlane(a1[qi].z, fl); qd[7] = __builtin_amdgcn_readlane(a1[qi].w, fl);
+      // the literal search for this one query by the whole wave, lanes over the
+      // candidates of its own rows [v1-tol, v1+tol]
+      const uint32_t quv1 = __builtin_amdgcn_readlane(uv1[qi], fl);
+      const int32_t u1 = (int32_t)(quv1 & 0xFFFF), v1 = (int32_t)(quv1 >> 16);
+      const us2 qlo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
+      const int32_t x0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + max(v1 - a.disp_tol, 0)]);
+      const int32_t x1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + min(v1 + a.disp_tol, s.H - 1) + 1]);
+      uint32_t k = 0xFFFFFFFFu;
+      for (int32_t x = x0 + lane; x < x1; x += 64) {
+        const int32_t cp = cpos[x];
+        k = min(k, tested_key_uniform_query(qd, qlo2, span2, cuv[cp], cdesc[2 * (int64_t)cp], cdesc[2 * (int64_t)cp + 1], (uint32_t)(cp - pbase)));
+      }
+      k = wave_min_u32(k);
+      if (lane == fl) kfin[qi] = k;
+    }
+  }
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    if (valid[qi] && ph == 0) {
+      // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
+      const int32_t r = (kfin[qi] == 0xFFFFFFFFu) ? 0 : cidx[pbase + (int32_t)(kfin[qi] & 0x7FFFFu)];
+      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[qp[qi]]] = r;
+    }
+  }
+}
+
+__device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
+                                          int32_t cset, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
+  const int32_t nrow = 4 * s.H;
+  const int32_t *__restrict__ qrs = s.row_start + (int64_t)qset * (nrow + 1);
   // tile -> (class, query range): classes are contiguous in row order
   int32_t cls_q0[5];
 #pragma unroll
   for (int32_t c = 0; c <= 4; c++) cls_q0[c] = __builtin_amdgcn_readfirstlane(qrs[c * s.H]);
-  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
-  uint2 *wM = sMeta + (threadIdx.x >> 6) * 64;
+  constexpr int T = VH_TILE_Q;
   for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));; tile += gridDim.x * 4) {
     int32_t c = -1, q0 = 0, q1 = 0, t = tile;
 #pragma unroll
     for (int32_t k = 0; k < 4; k++) {
-      const int32_t nt = (cls_q0[k + 1] - cls_q0[k] + 63) >> 6;
-      if (c < 0 && t < nt) { c = k; q0 = cls_q0[k] + 64 * t; q1 = min(cls_q0[k + 1], q0 + 64); }
+      const int32_t nt = (cls_q0[k + 1] - cls_q0[k] + T - 1) / T;
+      if (c < 0 && t < nt) { c = k; q0 = cls_q0[k] + T * t; q1 = min(cls_q0[k + 1], q0 + T); }
       if (c < 0) t -= nt;
     }
     if (c < 0) break;  // past the last tile (uniform)
-    const int32_t q = q0 + lane;
-    const bool valid = q < q1;
-    const int32_t ql = valid ? q : q0;
-    // row order holds bin positions; the records are gathered from the bin-ordered arrays
-    const int32_t qp = qpos[ql];
-    const uint2 qm = make_uint2(quv[qp], (uint32_t)qp);
-    const uint4 a0 = qdesc[2 * (int64_t)qp], a1 = qdesc[2 * (int64_t)qp + 1];
-    const int32_t u1 = qm.x & 0xFFFF, v1 = qm.x >> 16;
-    // window: u1 +- radius, v1 +- disp_tolerance; packed accept test as in the flow search
-    const us2 lo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
-    const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * a.disp_tol)};
-    const int32_t VLO = max(__builtin_amdgcn_readfirstlane(wave_min(valid ? v1 : 0x7FFFFFFF)) - a.disp_tol, 0);
-    const int32_t VHI = min(__builtin_amdgcn_readfirstlane(wave_max(valid ? v1 : -1)) + a.disp_tol, s.H - 1);
-    const int32_t r0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VLO]);
-    const int32_t r1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VHI + 1]);
-    // key = SAD << 16 | (bin-order position - class base) straight out of a
-    // v_sad_hi_u8 chain when the class holds < 2^16 candidates (see flow_tile),
-    // else SAD << 19 | position
     const int32_t *cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
-    const bool hi = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]) - pbase <= 0xFFFF && !a.wide_keys;
-    uint32_t best_key = 0xFFFFFFFFu;
-    for (int32_t rc = r0; rc < r1; rc += 64) {
-      const int32_t mcnt = min(64, r1 - rc);
-      const int32_t rl = min(rc + lane, r1 - 1);
-      const int32_t cp = cpos[rl];
-      const uint2 gm = make_uint2(cuv[cp], (uint32_t)(hi ? cp - pbase : cp));
-      const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
-      wM[lane] = gm; wD[2 * lane] = g0; wD[2 * lane + 1] = g1;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
-      // four candidates per trip (their LDS reads are issued together), then the rest
-      auto key_of = [&](auto hi_, const uint2 cm, const uint4 &b0, const uint4 &b1) -> uint32_t {
-        const us2 tt = as_us2(cm.x) - lo2;
-        const us2 mm = __builtin_elementwise_min(tt, span2);
-        const bool out = as_u32(tt) != as_u32(mm);
-        uint32_t key;
-        if (decltype(hi_)::value) {
-          key = sad4hi(a0.x, b0.x, cm.y);
-          key = sad4hi(a0.y, b0.y, key);
-          key = sad4hi(a0.z, b0.z, key);
-          key = sad4hi(a0.w, b0.w, key);
-          key = sad4hi(a1.x, b1.x, key);
-          key = sad4hi(a1.y, b1.y, key);
-          key = sad4hi(a1.z, b1.z, key);
-          key = sad4hi(a1.w, b1.w, key);
-        } else {
-          uint32_t sad = sad4(a0.x, b0.x, 0);
-          sad = sad4(a0.y, b0.y, sad);
-          sad = sad4(a0.z, b0.z, sad);
-          sad = sad4(a0.w, b0.w, sad);
-          sad = sad4(a1.x, b1.x, sad);
-          sad = sad4(a1.y, b1.y, sad);
-          sad = sad4(a1.z, b1.z, sad);
-          sad = sad4(a1.w, b1.w, sad);
-          key = (sad << 19) | cm.y;
-        }
-        return out ? 0xFFFFFFFFu : key;
-      };
-      auto consume = [&](auto hi_) {
-        int32_t j = 0;
-        for (; j + 4 <= mcnt; j += 4) {
-          uint2 cm[4];
-          uint4 b0[4], b1[4];
-#pragma unroll
-          for (int32_t k = 0; k < 4; k++) { cm[k] = wM[j + k]; b0[k] = wD[2 * (j + k)]; b1[k] = wD[2 * (j + k) + 1]; }
-          const uint32_t k0 = key_of(hi_, cm[0], b0[0], b1[0]), k1 = key_of(hi_, cm[1], b0[1], b1[1]);
-          const uint32_t k2 = key_of(hi_, cm[2], b0[2], b1[2]), k3 = key_of(hi_, cm[3], b0[3], b1[3]);
-          best_key = min(min(min(k0, k1), min(k2, k3)), best_key);
-        }
-        for (; j < mcnt; j++) best_key = min(best_key, key_of(hi_, wM[j], wD[2 * j], wD[2 * j + 1]));
-      };
-      if (hi) consume(std::true_type{});
-      else consume(std::false_type{});
-    }
-    if (valid) {
-      // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t bp = hi ? pbase + (int32_t)(best_key & 0xFFFFu) : (int32_t)(best_key & 0x7FFFFu);
-      const int32_t res = (best_key == 0xFFFFFFFFu) ? 0 : cidx[bp];
-      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[qm.y]] = res;
-    }
+    const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
+    if (pend - pbase <= 0x10000 && !a.wide_keys) rows_tile<VH_FLOW_Q, VH_FLOW_P, true>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
+    else rows_tile<VH_FLOW_Q, VH_FLOW_P, false>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
   }
+}
+
+// Every pass of a matching method in ONE launch (blockIdx.y = pass): the 1-d stereo
+// searches are chains of dependent L2 round trips around very little arithmetic
+// (~75 candidates per tile), the 2-d flow searches are bound by VALU issue; as
+// separate, serialised kernels the former cost as much time as ~half of the latter
+// for 3 % of its instructions.  Mixed on the same CUs the flow waves fill the issue
+// slots the stereo waves leave idle.  All passes of a method are independent of each
+// other (each is a pure function of its two feature sets).
+template <bool SPEC>
+__global__ void __launch_bounds__(256)
+match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
+  __shared__ uint4 sDesc[4 * 128];   // per wave: 64 staged candidates, first | second descriptor half
+  __shared__ uint32_t sAux[4 * 64];  // per wave: their u | v << 16 (tested flow loop) or key seeds (stereo)
+  const int32_t pass = blockIdx.y, stream = blockIdx.z;
+  const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
+  const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
+  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
+  uint32_t *wU = sAux + (threadIdx.x >> 6) * 64;
+  if (a.pass[pass].flow) flow_pass<SPEC>(s, a, pass, stream, qset, cset, wD, wU, best);
+  else rows_pass(s, a, pass, stream, qset, cset, wD, wU, best);
 }
 
 // ------------------------------------------------------------ match (prior term)
@@ -782,51 +866,25 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
 
 }  // namespace
 
-// The passes are split by search type: 2-d flow search (wave-uniform candidate
-// stream over bins) and 1-d stereo search (per-lane rows).
-static VhMatchArgs filter_passes(const VhMatchArgs &a, int32_t flow) {
-  VhMatchArgs r = a;
-  r.npass = 0;
-  for (int32_t k = 0; k < a.npass; k++)
-    if ((a.pass[k].flow != 0) == (flow != 0)) r.pass[r.npass++] = a.pass[k];
-  return r;
-}
-void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
-  VhMatchArgs sr = filter_passes(a, 0);
-  static const int wide = [] { const char *e = getenv("VH_FLOW_WIDE_KEYS"); return e ? atoi(e) : 0; }();
-  sr.wide_keys = wide;
-  if (!sr.npass) return;
-  dim3 grid(std::min(std::max(s.cap / 1024, 8), 1024), sr.npass, a.S);  // 4 tiles of 64 queries per workgroup per trip
-  hipLaunchKernelGGL(match_rows_kernel, grid, dim3(256), 0, st, s, sr, best);
-}
 void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, double v_, int32_t *best,
                            hipStream_t st) {
   hipLaunchKernelGGL(match_prior_kernel, dim3((s.cap + 127) / 128), dim3(128), 0, st, s, a, u_, v_, best);
 }
-void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
-  VhMatchArgs fl = filter_passes(a, 1);
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
+  if (!a.npass) return;
+  VhMatchArgs m = a;
   static const int wide = [] { const char *e = getenv("VH_FLOW_WIDE_KEYS"); return e ? atoi(e) : 0; }();
-  fl.wide_keys = wide;
-  if (!fl.npass) return;
-  // One workgroup per 4 tiles of the capacity-sized tile list (the kernel loops,
-  // so any grid is correct).  At typical densities ~75 % of these workgroups
-  // find no tile and exit at once; a tight grid (VH_FLOW_WGS=38) makes the flow
-  // search itself 20 % shorter but starves the detect stream beside it: 61.6 k
-  // vs 62.2 k pairs/s, and 58.4 k at 40 -- measured, so the full grid stays.
+  m.wide_keys = wide;
+  // One workgroup per 4 tiles of the capacity-sized tile list (the kernel loops, so
+  // any grid is correct; at typical densities most of these workgroups find no tile
+  // and exit at once).  VH_FLOW_WGS overrides (experiments).
   static const int wgs = [] { const char *e = getenv("VH_FLOW_WGS"); return e ? atoi(e) : 0; }();
   const int32_t gx = wgs > 0 ? wgs : (s.max_tiles + 3) / 4;
-  dim3 grid(gx, fl.npass, a.S);
-  // Dynamic-LDS padding (unused by the kernel) caps the flow search at 5 workgroups
-  // = 20 waves per CU.  Alone it runs as fast as at 8 waves/SIMD (it is VALU-issue
-  // bound); beside the detect stream it leaves that stream enough wave slots to
-  // finish frame t+1's detection inside the flow search of frame t instead of
-  // being starved until it ends: +5 % throughput measured (sweep 0..60000 B,
-  // VH_FLOW_LDS_PAD overrides).
-  static const int pad = [] { const char *e = getenv("VH_FLOW_LDS_PAD"); return e ? atoi(e) : VH_FLOW_LDS_PAD_DEFAULT; }();
-  // VH_FLOW_TESTED=1: the loop with the per-pair accept tests instead of the speculative one (same results)
+  dim3 grid(gx, m.npass, a.S);
+  // VH_FLOW_TESTED=1: the flow loop with the per-pair accept tests instead of the speculative one (same results)
   static const int tested = [] { const char *e = getenv("VH_FLOW_TESTED"); return e ? atoi(e) : 0; }();
-  if (tested) hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), (size_t)pad, st, s, fl, best);
-  else hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), (size_t)pad, st, s, fl, best);
+  if (tested) hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), 0, st, s, m, best);
+  else hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), 0, st, s, m, best);
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st) {

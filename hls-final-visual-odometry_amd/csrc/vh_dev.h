@@ -143,10 +143,9 @@ void vh_launch_bin_sort(const VhSets &s, int32_t set0, int32_t nsets, int32_t st
 void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, int32_t *list_ref,
                          hipStream_t st);
 
-void vh_launch_match_stereo(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
 void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, double v_, int32_t *best,
                            hipStream_t st);
-void vh_launch_match_flow(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st);
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,

@@ -279,7 +279,7 @@ int32_t vh_group_stream_wait_images(vh_group *g, void *hip_stream);
  * kernel launch while enabled).  vh_group_profile_read returns the
  * accumulated milliseconds and launch count of kernel `name`
  * ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill",
- *  "bin_sort", "match_stereo", "match_flow", "chain", "emit_matches") since the last reset. */
+ *  "bin_sort", "match", "chain", "emit_matches") since the last reset. */
 int32_t vh_group_profile_enable(vh_group *g, int32_t on);
 int32_t vh_group_profile_read(vh_group *g, const char *name, double *ms, int64_t *launches);
 int32_t vh_group_profile_reset(vh_group *g);

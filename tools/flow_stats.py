@@ -11,7 +11,7 @@ W, H = 1241, 376
 dims = [W, H, pkg.synth.bytes_per_line(W)]
 seq = pkg.synth.stereo_sequence(W, H, 3)
 m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 12)()
 for t, (l, r) in enumerate(seq):
     m.pushBack(l, r, dims, False)
     if t:
@@ -25,4 +25,6 @@ for t, (l, r) in enumerate(seq):
         print(f"step {t}: tiles {tiles} queries {nq} (fill {nq / max(tiles,1) / T:.2f}) columns/tile {ncol / max(tiles,1):.1f} chunks/tile {chunks / max(tiles,1):.1f} "
               f"candidates/tile {trips * 2 * P / max(tiles,1):.0f}  trips none/v/full {t0} {t1} {t2} ({t0 / trips:.2f} {t1 / trips:.2f} {t2 / trips:.2f})  "
               f"evaluated lane-pairs {trips * 2 * P * T:.3e}  re-searched queries {nredo} ({nredo / max(nq, 1):.4f})")
+        st, strips, sredo, sq = [int(x) for x in out[8:12]]
+        print(f"        stereo: tiles {st} queries {sq} candidates/tile {strips * 2 * P / max(st, 1):.0f} re-searched {sredo} ({sredo / max(sq, 1):.4f})")
 m.close()

@@ -30,7 +30,7 @@ os.makedirs(dst, exist_ok=True)
 
 NAMES = {"detect_nms_fast_kernel": "detect_nms", "detect_nms_kernel": "detect_nms", "emit_features_kernel": "emit_features",
          "bin_scan_kernel": "bin_scan", "bin_sort_kernel": "bin_sort", "bin_hist_kernel": "bin_hist", "bin_fill_kernel": "bin_fill",
-         "match_rows_kernel": "match_stereo", "match_kernel": "match_flow", "chain_kernel": "chain",
+         "match_kernel": "match", "chain_kernel": "chain",
          "emit_matches_kernel": "emit_matches", "flow_keep_kernel": "flow_keep"}
 
 
