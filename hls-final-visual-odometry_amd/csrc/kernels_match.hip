@@ -105,12 +105,17 @@ __device__ __forceinline__ void walk_region(const VhSets &s, const int32_t *__re
                                             int32_t VB1, int32_t ULO_MAX, int32_t UHI_MIN, int32_t VA0, int32_t VA1,
                                             Consume consume) {
   const int32_t lane = threadIdx.x & 63;
-  for (int32_t cb = UB0; cb <= UB1; cb += 64) {
-    const int32_t ncb = min(64, UB1 - cb + 1);
+  // When the v range covers every v-bin (2*radius >= H, as at KITTI size), the columns
+  // [UB0, UB1] are one contiguous run of positions: walk it as a single column -- fewer,
+  // fuller chunks and one rounding of the tail instead of one per column.
+  const bool merged = !TESTED && VB0 == 0 && VB1 == s.vbn - 1;
+  const int32_t UB1w = merged ? UB0 : UB1;
+  for (int32_t cb = UB0; cb <= UB1w; cb += 64) {
+    const int32_t ncb = min(64, UB1w - cb + 1);
     int32_t t_p0 = 0, t_p1 = 0, t_a0 = 0, t_a1 = 0;
     if (lane < ncb) {
       const int32_t row = (c * s.ubn + cb + lane) * s.vbn;
-      t_p0 = cbs[row + VB0]; t_p1 = cbs[row + VB1 + 1];
+      t_p0 = cbs[row + VB0]; t_p1 = merged ? cbs[(c * s.ubn + UB1 + 1) * s.vbn] : cbs[row + VB1 + 1];
       if (TESTED) {
         const int32_t ubx = cb + lane;
         const bool in_ = ubx * s.binsize >= ULO_MAX && ubx * s.binsize + s.binsize - 1 <= UHI_MIN;
