@@ -201,7 +201,7 @@ struct Group {
     if (rc != VH_OK) return rc;
     dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
     int64_t c = req_features > 0 ? req_features : std::max<int64_t>(4 * (int64_t)g.nblocks, 64);
-    if (c > (1 << 19) - 1) c = (1 << 19) - 1;  // match keys carry a 19-bit position
+    if (c > (1 << VH_MASK_IDX_BITS) - 1) c = (1 << VH_MASK_IDX_BITS) - 1;  // feature indices are packed into VH_MASK_IDX_BITS bits (flow pixel mask)
     cap = (int32_t)c;
     mcap = req_matches > 0 ? req_matches : cap;
 
@@ -448,7 +448,7 @@ struct Group {
         VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ps));
         epoch = 0;
       }
-      if (++epoch >= 4095) {
+      if (++epoch >= (1u << (32 - VH_MASK_IDX_BITS)) - 1) {
         VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ps));
         epoch = 1;
       }

@@ -158,21 +158,65 @@ __device__ __forceinline__ void walk_region(const VhSets &s, const int32_t *__re
 }
 
 // One candidate (this lane's) against ONE wave-uniform query with the literal accept
-// test of matcher.cpp:249: the key (SAD << 19 | position - pbase), or 0xFFFFFFFF.
+// test of matcher.cpp:249: the key (SAD << 32 | position - pbase), or ~0.
 // The slow, exact path behind the speculative searches below (lanes over candidates).
-__device__ __forceinline__ uint32_t tested_key_uniform_query(const uint32_t (&qd)[8], us2 lo2, us2 span2, uint32_t uv2,
+__device__ __forceinline__ uint64_t tested_key_uniform_query(const uint32_t (&qd)[8], us2 lo2, us2 span2, uint32_t uv2,
                                                              const uint4 &b0, const uint4 &b1, uint32_t relpos) {
   const us2 t = as_us2(uv2) - lo2;
   const us2 m = __builtin_elementwise_min(t, span2);
   uint32_t sad = sad4(qd[0], b0.x, 0);
   sad = sad4(qd[1], b0.y, sad); sad = sad4(qd[2], b0.z, sad); sad = sad4(qd[3], b0.w, sad);
   sad = sad4(qd[4], b1.x, sad); sad = sad4(qd[5], b1.y, sad); sad = sad4(qd[6], b1.z, sad); sad = sad4(qd[7], b1.w, sad);
-  return as_u32(t) != as_u32(m) ? 0xFFFFFFFFu : ((sad << 19) | relpos);
+  return as_u32(t) != as_u32(m) ? ~0ull : (((uint64_t)sad << 32) | relpos);
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t k) {
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t k, int32_t d) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int32_t)(uint32_t)k, d), hi = (uint32_t)__shfl_xor((int32_t)(uint32_t)(k >> 32), d);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {
 #pragma unroll
-  for (int32_t d = 32; d >= 1; d >>= 1) k = min(k, (uint32_t)__shfl_xor((int32_t)k, d));
+  for (int32_t d = 32; d >= 1; d >>= 1) k = min(k, shfl_xor_u64(k, d));
   return k;
+}
+
+// Match keys.  The minimum of (SAD, bin-order position relative to the first position of
+// the class) in lexicographic order is findMatch's first strict minimum (matcher.cpp:264),
+// because positions in bin order are the reference's visiting order.  Three encodings:
+//   KEY_HI16  SAD << 16 | position: straight out of a v_sad_hi_u8 chain (it accumulates at
+//             bit 16) seeded with the position; classes of < 2^16 - 64 features
+//   KEY_W19   SAD << 19 | position from a v_sad_u8 chain and one v_lshl_or_b32
+//             (SAD <= 8160 < 2^13); classes of <= VH_CLASS_POS_MAX features
+//   KEY_64    SAD << 32 | position in 64 bits (compare + two selects per candidate):
+//             any class size -- only images of more than 524 224 NMS blocks can need it
+enum { KEY_HI16 = 0, KEY_W19 = 1, KEY_64 = 2 };
+template <int KM> struct KeyT { typedef uint32_t type; };
+template <> struct KeyT<KEY_64> { typedef uint64_t type; };
+template <int KM>
+__device__ __forceinline__ typename KeyT<KM>::type sad_key(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1, uint32_t seed) {
+  if (KM == KEY_HI16) {
+    uint32_t key = sad4hi(a0.x, b0.x, seed);
+    key = sad4hi(a0.y, b0.y, key); key = sad4hi(a0.z, b0.z, key); key = sad4hi(a0.w, b0.w, key);
+    key = sad4hi(a1.x, b1.x, key); key = sad4hi(a1.y, b1.y, key); key = sad4hi(a1.z, b1.z, key); key = sad4hi(a1.w, b1.w, key);
+    return (typename KeyT<KM>::type)key;
+  }
+  uint32_t sad = sad4(a0.x, b0.x, 0);
+  sad = sad4(a0.y, b0.y, sad); sad = sad4(a0.z, b0.z, sad); sad = sad4(a0.w, b0.w, sad);
+  sad = sad4(a1.x, b1.x, sad); sad = sad4(a1.y, b1.y, sad); sad = sad4(a1.z, b1.z, sad); sad = sad4(a1.w, b1.w, sad);
+  if (KM == KEY_W19) return (typename KeyT<KM>::type)((sad << 19) | seed);
+  return (typename KeyT<KM>::type)(((uint64_t)sad << 32) | seed);
+}
+// any encoding -> SAD << 32 | position (or ~0 for "none")
+template <int KM>
+__device__ __forceinline__ uint64_t key_to_64(typename KeyT<KM>::type k) {
+  if (KM == KEY_64) return (uint64_t)k;
+  if ((uint32_t)k == 0xFFFFFFFFu) return ~0ull;
+  const uint32_t kk = (uint32_t)k;
+  return KM == KEY_HI16 ? (((uint64_t)(kk >> 16) << 32) | (kk & 0xFFFFu)) : (((uint64_t)(kk >> 19) << 32) | (kk & 0x7FFFFu));
+}
+__device__ __forceinline__ int32_t key_mode_of(int32_t class_count, int32_t wide_keys) {
+  // (+64: the copies past the end of a run carry positions up to 63 past it)
+  if (class_count + 64 <= 0x10000 && !wide_keys) return KEY_HI16;
+  return class_count <= VH_CLASS_POS_MAX && wide_keys < 2 ? KEY_W19 : KEY_64;
 }
 
 // One tile of the flow search.
@@ -215,10 +259,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k) {
 // original at a larger position, so their keys are larger than the original's
 // key and never change a minimum.  That lets every range of the chunk be rounded
 // outward to whole trips of 2*P candidates without any tail code.
-template <int Q, int P, bool HI, bool SPEC>
+template <int Q, int P, int KM, bool SPEC>
 __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream,
                                           int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c,
-                                          int32_t pbase, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
+                                          int32_t pbase, int32_t pcnt, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
   constexpr int L = 64 / P;
   static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile (row-wise window reduction)");
   constexpr int TRIP = 2 * P;  // candidates per trip: two steps, joined by one v_min3_u32 per query
@@ -237,7 +281,9 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
   uint32_t uv1[Q];
   int32_t v_lo[Q];
   us2 lo2[Q];
-  uint32_t best_key[Q];
+  typedef typename KeyT<KM>::type key_t;
+  const key_t KNONE = (key_t)~(key_t)0;
+  key_t best_key[Q];
   int32_t umin = 0x7FFFFFFF, umax = -1, vmin = 0x7FFFFFFF, vmax = -1;
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
@@ -254,7 +300,7 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
     // Exact because coordinates are < 2^14 and radii <= 2^14 (|u2-u1|+r < 2^15).
     v_lo[qi] = v1 - rv;
     lo2[qi] = us2{(unsigned short)(u1 - a.radius), (unsigned short)v_lo[qi]};
-    best_key[qi] = 0xFFFFFFFFu;
+    best_key[qi] = KNONE;
     // (lanes past q1 repeat query q0: it is valid, so the extrema are unchanged)
     umin = min(umin, u1); umax = max(umax, u1); vmin = min(vmin, v1); vmax = max(vmax, v1);
   }
@@ -281,15 +327,9 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
   const int32_t VA0 = SPEC ? 0 : max(VB0, (max(VLO_MAX, 0) + s.binsize - 1) / s.binsize);
   const int32_t VA1 = SPEC ? 0 : min(VB1, (VHI_MIN + 1) / s.binsize - 1);
 
-  // best = min over candidates of (SAD << 16 | position - pbase), pbase = first
-  // position of the class: positions in bin order are the reference's visiting
-  // order, so this key reproduces its strict-< first-minimum rule (matcher.cpp:264).
-  // HI: the key comes straight out of a v_sad_hi_u8 chain (it accumulates at bit 16)
-  // seeded with the relative position; needs < 2^16 positions per class.  Otherwise
-  // (SAD << 19 | position - pbase) from a v_sad_u8 chain and one v_lshl_or_b32
-  // (SAD <= 8160 < 2^13, < 2^19 positions per class).
+  // best = min over candidates of the key (sad_key): SAD, then bin-order position.
   // TEST: 2 = full (u,v) window test, 1 = v only, 0 = none
-  auto make_key = [&](auto test, int32_t qi, uint32_t uv2, const uint4 &b0, const uint4 &b1, uint32_t seed) -> uint32_t {
+  auto make_key = [&](auto test, int32_t qi, uint32_t uv2, const uint4 &b0, const uint4 &b1, uint32_t seed) -> key_t {
     constexpr int TEST = decltype(test)::value;
     bool out = false;
     if (TEST == 2) {
@@ -299,28 +339,8 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
     } else if (TEST == 1) {
       out = (uint32_t)((int32_t)(uv2 >> 16) - v_lo[qi]) > (uint32_t)(2 * rv);
     }
-    uint32_t key;
-    if (HI) {
-      key = sad4hi(a0[qi].x, b0.x, seed);
-      key = sad4hi(a0[qi].y, b0.y, key);
-      key = sad4hi(a0[qi].z, b0.z, key);
-      key = sad4hi(a0[qi].w, b0.w, key);
-      key = sad4hi(a1[qi].x, b1.x, key);
-      key = sad4hi(a1[qi].y, b1.y, key);
-      key = sad4hi(a1[qi].z, b1.z, key);
-      key = sad4hi(a1[qi].w, b1.w, key);
-    } else {
-      uint32_t sad = sad4(a0[qi].x, b0.x, 0);
-      sad = sad4(a0[qi].y, b0.y, sad);
-      sad = sad4(a0[qi].z, b0.z, sad);
-      sad = sad4(a0[qi].w, b0.w, sad);
-      sad = sad4(a1[qi].x, b1.x, sad);
-      sad = sad4(a1[qi].y, b1.y, sad);
-      sad = sad4(a1[qi].z, b1.z, sad);
-      sad = sad4(a1[qi].w, b1.w, sad);
-      key = (sad << 19) | seed;
-    }
-    return (TEST != 0 && out) ? 0xFFFFFFFFu : key;
+    const key_t key = sad_key<KM>(a0[qi], a1[qi], b0, b1, seed);
+    return (TEST != 0 && out) ? KNONE : key;
   };
   VH_STAT(0, 1); VH_STAT(5, q1 - q0); VH_STAT(6, UB1 - UB0 + 1);
   walk_region<!SPEC, !SPEC>(s, cbs, cuv, cdesc, c, UB0, UB1, VB0, VB1, ULO_MAX, UHI_MIN, VA0, VA1,
@@ -344,7 +364,7 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
           if (decltype(test)::value != 0) { uA = ru[0]; uB = ru[P]; }
 #pragma unroll
           for (int32_t qi = 0; qi < Q; qi++) {
-            const uint32_t kA = make_key(test, qi, uA, dA0, dA1, seedA), kB = make_key(test, qi, uB, dB0, dB1, seedB);
+            const key_t kA = make_key(test, qi, uA, dA0, dA1, seedA), kB = make_key(test, qi, uB, dB0, dB1, seedB);
             best_key[qi] = min(min(kA, kB), best_key[qi]);
           }
           rd += TRIP; ru += TRIP; seedA += TRIP; seedB += TRIP;
@@ -365,21 +385,19 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
         run(std::integral_constant<int, 2>{}, jend);
       }
     });
-  uint32_t kfin[Q];
+  uint64_t kfin[Q];  // SAD << 32 | relative position, ~0: none
   bool redo[Q];
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
     // join the phases: lanes l, l+L, l+2L, .. hold partial minima of the same query
-    uint32_t k = best_key[qi];
+    uint64_t k = key_to_64<KM>(best_key[qi]);
 #pragma unroll
-    for (int32_t d = L; d < 64; d <<= 1) k = min(k, (uint32_t)__shfl_xor((int32_t)k, d));
-    // wide form from here on: SAD << 19 | relative position
-    if (HI && k != 0xFFFFFFFFu) k = ((k >> 16) << 19) | (k & 0xFFFFu);
+    for (int32_t d = L; d < 64; d <<= 1) k = min(k, shfl_xor_u64(k, d));
     kfin[qi] = k;
     redo[qi] = false;
-    if (SPEC && valid[qi] && ph == 0 && k != 0xFFFFFFFFu) {
+    if (SPEC && valid[qi] && ph == 0 && k != ~0ull) {
       // the winner over the union region: inside this query's own window?
-      const us2 t = as_us2(cuv[pbase + (int32_t)(k & 0x7FFFFu)]) - lo2[qi];
+      const us2 t = as_us2(cuv[pbase + min((int32_t)(uint32_t)k, pcnt - 1)]) - lo2[qi];
       const us2 m = __builtin_elementwise_min(t, span2);
       redo[qi] = as_u32(t) != as_u32(m);
     }
@@ -402,13 +420,13 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
         const uint32_t quv1 = __builtin_amdgcn_readlane(uv1[qi], fl);
         const int32_t u1 = (int32_t)(quv1 & 0xFFFF), v1 = (int32_t)(quv1 >> 16);
         const us2 qlo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - rv)};
-        uint32_t k = 0xFFFFFFFFu;
+        uint64_t k = ~0ull;
         walk_region<false, true>(s, cbs, cuv, cdesc, c, bin_of(u1 - a.radius, s.ubn), bin_of(u1 + a.radius, s.ubn),
                                  bin_of(v1 - rv, s.vbn), bin_of(v1 + rv, s.vbn), 0, 0, 0, 0,
           [&](int32_t, int32_t, int32_t, int32_t, int32_t pl, uint32_t gu, const uint4 &g0, const uint4 &g1) {
             k = min(k, tested_key_uniform_query(qd, qlo2, span2, gu, g0, g1, (uint32_t)(pl - pbase)));
           });
-        k = wave_min_u32(k);
+        k = wave_min_u64(k);
         if (lane == fl) kfin[qi] = k;
       }
     }
@@ -417,7 +435,7 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
   for (int32_t qi = 0; qi < Q; qi++) {
     if (valid[qi] && ph == 0) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t r = (kfin[qi] == 0xFFFFFFFFu) ? 0 : cidx[pbase + (int32_t)(kfin[qi] & 0x7FFFFu)];
+      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + min((int32_t)(uint32_t)kfin[qi], pcnt - 1)];
       best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q0 + L * qi + l]] = r;
     }
   }
@@ -436,9 +454,10 @@ __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a,
     const int32_t *cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
-    // (+64: the copies past the end of a column carry positions up to 63 past it)
-    if (pend - pbase + 64 <= 0x10000 && !a.wide_keys) flow_tile<VH_FLOW_Q, VH_FLOW_P, true, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
-    else flow_tile<VH_FLOW_Q, VH_FLOW_P, false, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
+    const int32_t km = key_mode_of(pend - pbase, a.wide_keys);
+    if (km == KEY_HI16) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
+    else if (km == KEY_W19) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
+    else flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
   }
 }
 
@@ -460,9 +479,9 @@ __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a,
 // order the rows are walked.  Round 1 used 64-query tiles with the test in the
 // loop: 100 evaluated candidates and 13 instructions per query and candidate
 // where ~15 candidates are inside the window; this form evaluates ~70 at 9.4.
-template <int Q, int P, bool HI>
+template <int Q, int P, int KM>
 __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
-                                          int32_t cset, int32_t q0, int32_t q1, int32_t c, int32_t pbase, uint4 *wD,
+                                          int32_t cset, int32_t q0, int32_t q1, int32_t c, int32_t pbase, int32_t pcnt, uint4 *wD,
                                           uint32_t *wU, int32_t *__restrict__ best) {
   constexpr int L = 64 / P;
   static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile");
@@ -484,7 +503,8 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   uint4 a0[Q], a1[Q];
   uint32_t uv1[Q];
   int32_t qp[Q];
-  uint32_t best_key[Q];
+  typedef typename KeyT<KM>::type key_t;
+  key_t best_key[Q];
   int32_t vmin = 0x7FFFFFFF, vmax = -1;
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
@@ -494,7 +514,7 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
     uv1[qi] = quv[qp[qi]];
     a0[qi] = qdesc[2 * (int64_t)qp[qi]]; a1[qi] = qdesc[2 * (int64_t)qp[qi] + 1];
     const int32_t v1 = uv1[qi] >> 16;
-    best_key[qi] = 0xFFFFFFFFu;
+    best_key[qi] = (key_t)~(key_t)0;
     vmin = min(vmin, v1); vmax = max(vmax, v1);
   }
   vmin = __builtin_amdgcn_readfirstlane(row16_allreduce<false>(vmin));
@@ -503,30 +523,6 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   const int32_t VLO = max(vmin - a.disp_tol, 0), VHI = min(vmax + a.disp_tol, s.H - 1);
   const int32_t r0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VLO]);
   const int32_t r1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VHI + 1]);
-  auto make_key = [&](int32_t qi, const uint4 &b0, const uint4 &b1, uint32_t seed) -> uint32_t {
-    uint32_t key;
-    if (HI) {
-      key = sad4hi(a0[qi].x, b0.x, seed);
-      key = sad4hi(a0[qi].y, b0.y, key);
-      key = sad4hi(a0[qi].z, b0.z, key);
-      key = sad4hi(a0[qi].w, b0.w, key);
-      key = sad4hi(a1[qi].x, b1.x, key);
-      key = sad4hi(a1[qi].y, b1.y, key);
-      key = sad4hi(a1[qi].z, b1.z, key);
-      key = sad4hi(a1[qi].w, b1.w, key);
-    } else {
-      uint32_t sad = sad4(a0[qi].x, b0.x, 0);
-      sad = sad4(a0[qi].y, b0.y, sad);
-      sad = sad4(a0[qi].z, b0.z, sad);
-      sad = sad4(a0[qi].w, b0.w, sad);
-      sad = sad4(a1[qi].x, b1.x, sad);
-      sad = sad4(a1[qi].y, b1.y, sad);
-      sad = sad4(a1[qi].z, b1.z, sad);
-      sad = sad4(a1[qi].w, b1.w, sad);
-      key = (sad << 19) | seed;
-    }
-    return key;
-  };
   for (int32_t rc = r0; rc < r1; rc += 64) {
     const int32_t mcnt = min(64, r1 - rc);
     const int32_t cp = cpos[min(rc + lane, r1 - 1)];  // slots past the end repeat the last candidate: same key, harmless
@@ -543,26 +539,25 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
       const uint32_t sA = ru[0], sB = ru[P];
 #pragma unroll
       for (int32_t qi = 0; qi < Q; qi++)
-        best_key[qi] = min(min(make_key(qi, dA0, dA1, sA), make_key(qi, dB0, dB1, sB)), best_key[qi]);
+        best_key[qi] = min(min(sad_key<KM>(a0[qi], a1[qi], dA0, dA1, sA), sad_key<KM>(a0[qi], a1[qi], dB0, dB1, sB)), best_key[qi]);
       rd += TRIP; ru += TRIP;
     }
   }
   // join the phases, test the winner against the query's own window, search again where it fails
   const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * a.disp_tol)};
-  uint32_t kfin[Q];
+  uint64_t kfin[Q];  // SAD << 32 | relative position, ~0: none
   bool redo[Q];
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
-    uint32_t k = best_key[qi];
+    uint64_t k = key_to_64<KM>(best_key[qi]);
 #pragma unroll
-    for (int32_t d = L; d < 64; d <<= 1) k = min(k, (uint32_t)__shfl_xor((int32_t)k, d));
-    if (HI && k != 0xFFFFFFFFu) k = ((k >> 16) << 19) | (k & 0xFFFFu);
+    for (int32_t d = L; d < 64; d <<= 1) k = min(k, shfl_xor_u64(k, d));
     kfin[qi] = k;
     redo[qi] = false;
-    if (valid[qi] && ph == 0 && k != 0xFFFFFFFFu) {
+    if (valid[qi] && ph == 0 && k != ~0ull) {
       const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
       const us2 lo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
-      const us2 t = as_us2(cuv[pbase + (int32_t)(k & 0x7FFFFu)]) - lo2;
+      const us2 t = as_us2(cuv[pbase + min((int32_t)(uint32_t)k, pcnt - 1)]) - lo2;
       const us2 m = __builtin_elementwise_min(t, span2);
       redo[qi] = as_u32(t) != as_u32(m);
     }
@@ -586,12 +581,12 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
       const us2 qlo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
       const int32_t x0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + max(v1 - a.disp_tol, 0)]);
       const int32_t x1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + min(v1 + a.disp_tol, s.H - 1) + 1]);
-      uint32_t k = 0xFFFFFFFFu;
+      uint64_t k = ~0ull;
       for (int32_t x = x0 + lane; x < x1; x += 64) {
         const int32_t cp = cpos[x];
         k = min(k, tested_key_uniform_query(qd, qlo2, span2, cuv[cp], cdesc[2 * (int64_t)cp], cdesc[2 * (int64_t)cp + 1], (uint32_t)(cp - pbase)));
       }
-      k = wave_min_u32(k);
+      k = wave_min_u64(k);
       if (lane == fl) kfin[qi] = k;
     }
   }
@@ -599,7 +594,7 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   for (int32_t qi = 0; qi < Q; qi++) {
     if (valid[qi] && ph == 0) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t r = (kfin[qi] == 0xFFFFFFFFu) ? 0 : cidx[pbase + (int32_t)(kfin[qi] & 0x7FFFFu)];
+      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + min((int32_t)(uint32_t)kfin[qi], pcnt - 1)];
       best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[qp[qi]]] = r;
     }
   }
@@ -626,8 +621,10 @@ __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a,
     const int32_t *cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
-    if (pend - pbase <= 0x10000 && !a.wide_keys) rows_tile<VH_FLOW_Q, VH_FLOW_P, true>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
-    else rows_tile<VH_FLOW_Q, VH_FLOW_P, false>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, wD, wU, best);
+    const int32_t km = key_mode_of(pend - pbase, a.wide_keys);
+    if (km == KEY_HI16) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
+    else if (km == KEY_W19) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
+    else rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
   }
 }
 
@@ -715,7 +712,7 @@ __device__ __forceinline__ void count_chunk(bool keep, int32_t *counter) {
 //                                             u1p >= u2p and u1c >= u2c
 // For flow the reference additionally keeps only the FIRST match per pixel of
 // the current image (mask M, matcher.cpp:331-334): every closing feature bids
-// for its pixel with atomicMax(epoch<<20 | (0xFFFFF - i1c)); the lowest i1c of
+// for its pixel with atomicMax(epoch << 24 | (2^24 - 1 - i1c)); the lowest i1c of
 // this epoch wins, and no clearing between frames is needed.
 __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int32_t *__restrict__ best,
                              int4 *__restrict__ chain, uint32_t *__restrict__ mask, uint32_t epoch,
@@ -739,7 +736,7 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
         r = make_int4(i1p, -1, i, -1);
         const int32_t *f = s.feat + ((int64_t)set1c * s.cap + i) * 12;
         atomicMax(&mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]],
-                  (epoch << 20) | (0xFFFFFu - (uint32_t)i));
+                  (epoch << VH_MASK_IDX_BITS) | (((1u << VH_MASK_IDX_BITS) - 1u) - (uint32_t)i));
       }
     }
     out[i] = r;
@@ -784,7 +781,7 @@ __global__ void flow_keep_kernel(VhSets s, VhMatchArgs a, int4 *__restrict__ cha
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n1c; i += gridDim.x * blockDim.x) {
     const int4 r = ch[i];
     const int32_t *f = s.feat + ((int64_t)set1c * s.cap + i) * 12;
-    const bool win = r.z >= 0 && mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]] == ((epoch << 20) | (0xFFFFFu - (uint32_t)i));
+    const bool win = r.z >= 0 && mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]] == ((epoch << VH_MASK_IDX_BITS) | (((1u << VH_MASK_IDX_BITS) - 1u) - (uint32_t)i));
     if (r.z >= 0 && !win) ch[i].z = -2;
     count_chunk(win, mchunk + stream * nchm + (i >> 8));
   }

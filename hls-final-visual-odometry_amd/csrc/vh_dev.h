@@ -44,6 +44,16 @@
 #endif
 #define VH_TILE_Q (64 * VH_FLOW_Q / VH_FLOW_P)  // queries per flow-search tile
 #define VH_NO_CODE 0xFFFFu
+// 32-bit match keys SAD << 19 | (bin-order position - first position of the class) serve classes
+// of up to 2^19 - 64 features per set (the staged chunks of the searches repeat the last candidate
+// of a run under positions up to 63 past it); larger classes take 64-bit keys (kernels_match.hip).
+// The detector yields at most one feature per class and NMS block, so only images of more than
+// 524 224 blocks can need those.
+#define VH_CLASS_POS_BITS 19
+#define VH_CLASS_POS_MAX ((1 << VH_CLASS_POS_BITS) - 64)
+// first-writer pixel mask of the flow method: epoch << 24 | (2^24 - 1 - i1c); also the
+// largest feature capacity per image (2^24 - 1)
+#define VH_MASK_IDX_BITS 24
 
 struct VhGeom {
   // full-resolution image
@@ -96,7 +106,7 @@ struct VhMatchArgs {
   int32_t pair_cur;  // ring slots: current frame | previous frame << 8
   int32_t S;
   int32_t radius, disp_tol;
-  int32_t wide_keys;  // 1: never use the 16-bit relative position keys of the flow search (VH_FLOW_WIDE_KEYS=1; test hook)
+  int32_t wide_keys;  // test hook (VH_FLOW_WIDE_KEYS): 1 = never the 16-bit position keys, 2 = always the 64-bit keys
 };
 
 __host__ __device__ inline int32_t vh_set_id(int32_t S, int32_t pair, int32_t stream, int32_t cam) {

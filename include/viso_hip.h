@@ -96,7 +96,8 @@ void vh_default_params(vh_params *p);
  * Envelope (VH_ERR_UNSUPPORTED outside): 1 <= nms_n <= 32, match_binsize >= 1,
  * 0 <= match_radius <= 16384, 0 <= match_disp_tolerance <= 16384, nms_tau >= 0,
  * images up to 16384 x 16384.  max_features/max_matches = 0 select the
- * worst-case capacity for the pushed image size (4 per NMS block).
+ * worst-case capacity for the pushed image size (4 per NMS block), clamped to
+ * 16 777 215 features per image.
  * When a pushed image yields more features than the capacity, the records
  * beyond it are dropped, matching runs on the truncated sets, and
  * vh_get_matches / vh_group_get_matches(_all) / vh_group_wait_download return

@@ -499,15 +499,28 @@ def test_dims_change_starts_a_new_sequence(pkg, ob, oracle, gpu):
 
 
 @pytest.mark.gpu
-def test_flow_search_wide_key_path(gpu):
-    """The flow search builds (SAD << 16 | relative position) keys on v_sad_hi_u8
-    when a class holds fewer than 2^16 candidates, else (SAD << 19 | position).
-    The second path is forced here (VH_FLOW_WIDE_KEYS=1, read once per process,
-    hence the subprocess) and must pass the same parity cases."""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_flow_search_wide_key_path(mode, gpu):
+    """The searches build (SAD << 16 | class-relative position) keys on v_sad_hi_u8 when a class
+    holds fewer than 2^16 - 64 candidates, (SAD << 19 | position) up to 2^19 - 64 and 64-bit keys
+    beyond.  The second and third encodings are forced here (VH_FLOW_WIDE_KEYS=1 / 2, read once
+    per process, hence the subprocess) and must pass the same parity cases."""
     import subprocess, sys
-    env = dict(os.environ, VH_FLOW_WIDE_KEYS="1")
+    env = dict(os.environ, VH_FLOW_WIDE_KEYS=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "golden or random_configs or tie_break or ring_buffer"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_flow_search_tested_loop_path(gpu):
+    """VH_FLOW_TESTED=1 selects the flow loop with the per-pair accept tests (three test classes
+    per bin) instead of the speculative one: same results."""
+    import subprocess, sys
+    env = dict(os.environ, VH_FLOW_TESTED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "golden or random_configs or tie_break or ring_buffer or kitti"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 
@@ -663,3 +676,32 @@ def test_4k_stereo_quad_small_bins(pkg, ob, oracle, gpu):
     _check_match_properties(pkg, oracle, po, dims, f, got, 2, np.random.default_rng(4), 200)
     ok = (got["u1p"] - got["u2p"] == 14) & (got["u1c"] - got["u2c"] == 14)
     assert ok.mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_4k_dense_maxima_beyond_the_old_envelope(pkg, ob, oracle, gpu):
+    """configs[4], "dense maxima": a 3840x2160 frame pair of the blur-1 / gain-4 texture at
+    nms_n = 2 -- more than 2^19 features per image (round 1 refused this with VH_ERR_CAPACITY).
+    Features exact on both frames, the stereo-type table and a sample of the flow table exact
+    vs the oracle, flow matches through the size-independent properties."""
+    W, H = 3840, 2160
+    dims = [W, H, 3840]
+    over = {"nms_n": 2, "match_binsize": 25, "match_radius": 60}
+    p, po = pkg.Params.default(**over), ob.Params.default(**over)
+    Ip = pkg.synth.frame(W, H, 0, 0, 1, 4, 9); Ic = pkg.synth.frame(W, H, 3, 1, 1, 4, 9)
+    m = pkg.Matcher(p, outlier_removal=False)
+    m.pushBack(Ip, None, dims, False)
+    m.pushBack(Ic, None, dims, False)
+    m.matchFeatures(pkg.METHOD_FLOW)
+    got = m.getMatches()
+    fp, fc = m.getFeatures(pkg.SET_1P), m.getFeatures(pkg.SET_1C)
+    m.close()
+    assert len(fc) > (1 << 19)
+    assert np.array_equal(fp, oracle.compute_features(po, Ip, dims)[1])
+    assert np.array_equal(fc, oracle.compute_features(po, Ic, dims)[1])
+    assert np.array_equal(pkg.match_all(p, dims, fc, fp, flow=False), oracle.match_all(po, dims, fc, fp, flow=False))
+    f = [fp, np.zeros((0, 12), np.int32), fc, np.zeros((0, 12), np.int32)]
+    _check_match_properties(pkg, oracle, po, dims, f, got, 0, np.random.default_rng(8), 300)
+    assert len(got) > 300000
+    pix = got["v1c"].astype(np.int64) * W + got["u1c"].astype(np.int64)
+    assert len(np.unique(pix)) == len(pix)
