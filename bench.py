@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct frames per stream kept in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
     args = ap.parse_args()
@@ -234,7 +235,8 @@ def main():
     stream = torch.cuda.current_stream()
     grp = pkg.StreamGroup(S, pkg.Params.default(**wl["params"]), device=local_rank, max_features=wl["cap"],
                           max_matches=wl["cap"])
-    grp.setStream(stream.cuda_stream)  # orders the group's work after this stream's (the frame upload)
+    # every pushBack is ordered after this stream (handle 0, torch's default stream, included): the frames were uploaded on it
+    grp.setStream(stream.cuda_stream)
 
     def step(k):
         t = k % T
@@ -251,26 +253,49 @@ def main():
     k = 0
     for _ in range(args.warmup):
         step(k); k += 1
-    grp.profileEnable(True)
-    grp.profileReset()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):  # the timed region: no per-kernel events in it
         step(k); k += 1
     fence()
     dt = time.perf_counter() - t0
-    grp.profileEnable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
-    # per-kernel device time over the timed region (HIP events on the launch stream)
-    prof = {}
-    for name in KERNELS:
-        ms, n = grp.profileRead(name)
-        if n:
-            prof[name] = {"ms_total": ms, "launches": n, "us_per_launch": 1e3 * ms / n}
+    # per-kernel device time: the same loop once more with HIP events recorded around every
+    # launch on the stream it is launched on (two internal streams: detect of frame t+1 overlaps
+    # match of frame t, so these durations include what the other stream does to the kernel)
+    def profiled(group, n, kk):
+        group.profileReset(); group.profileEnable(True)
+        for _ in range(n):
+            tq = kk % T
+            group.pushBackDevice(frames[tq, 0].data_ptr(), frames[tq, 1].data_ptr(), stride, dims, False)
+            group.matchFeatures(pkg.METHOD_QUAD)
+            kk += 1
+        group.synchronize(); torch.cuda.synchronize()
+        group.profileEnable(False)
+        out_ = {}
+        for name in KERNELS:
+            ms, n_ = group.profileRead(name)
+            if n_:
+                out_[name] = {"ms_total": ms, "launches": n_, "us_per_launch": 1e3 * ms / n_}
+        return out_
+    prof = profiled(grp, args.steps, k)
+    k += args.steps
+    # ... and exclusive durations: a second group whose kernels all run on ONE stream (VH_SERIAL=1)
+    prof_excl = {}
+    if not args.no_exclusive and rank == 0:
+        os.environ["VH_SERIAL"] = "1"
+        g2 = pkg.StreamGroup(S, pkg.Params.default(**wl["params"]), device=local_rank, max_features=wl["cap"], max_matches=wl["cap"])
+        os.environ.pop("VH_SERIAL")
+        g2.setStream(stream.cuda_stream)
+        for w_ in range(3):
+            g2.pushBackDevice(frames[w_ % T, 0].data_ptr(), frames[w_ % T, 1].data_ptr(), stride, dims, False)
+            g2.matchFeatures(pkg.METHOD_QUAD)
+        prof_excl = profiled(g2, min(args.steps, 12), 3)
+        g2.close()
     nf, nm = grp.getCounts()
     wl_radius = pkg.Params.default(**wl["params"]).match_radius
     last = (k - 1) % T
@@ -288,18 +313,27 @@ def main():
         if dom:
             sec = prof[dom]["us_per_launch"] * 1e-6
             achieved = S * B_pair / sec / 1e9
-            traffic = None
+            # HBM bytes of that kernel per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+            # (tools/profile_round.sh -> tools/summarize_profiles.py): reported only when they were
+            # taken on THIS build of the library (sha256) with this number of streams
+            traffic, traffic_src = None, None
             tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tj):
                 try:
+                    import hashlib
                     tr = json.load(open(tj))
-                    if tr.get("streams") == S and tr.get("kernel") == dom:
+                    lib_sha = hashlib.sha256(open(pkg.LIB_PATH, "rb").read()).hexdigest()
+                    if tr.get("streams") == S and tr.get("kernel") == dom and tr.get("lib_sha256") == lib_sha:
                         traffic = tr.get("hbm_bytes_per_launch")
+                        traffic_src = f"profiles/traffic_latest.json ({tr.get('tag')}, lib {lib_sha[:12]})"
+                    else:
+                        traffic_src = "profiles/traffic_latest.json is from another build or stream count: not reported"
                 except Exception:
                     traffic = None
-            # Context for the HBM figure: the flow search's compulsory v_sad_u8 work against the
-            # rate tools/ubench_valu.hip measured for that instruction (profiles/r01_ubench_valu.txt:
-            # 4.86 SIMD-cycles at the nominal 2.4 GHz, 1024 SIMDs) -- 8 SADs per in-window pair
+            # What binds: the searches' compulsory v_sad_u8 work against the issue rate of that
+            # instruction (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt: 4.27 SIMD cycles per
+            # wave-instruction at >= 2 waves per SIMD, i.e. half rate, 5.26e11 wave-instructions/s over
+            # the 1024 SIMDs at the 2.2 GHz the chip holds under it) -- 8 SADs per in-window pair
             valu = None
             if dom == "match" and nfm.mean() < 20000:  # (the pair count below is O(N^2) host work)
                 pairs_ = []
@@ -307,14 +341,25 @@ def main():
                     f = [grp.getFeatures(s_, w_) for w_ in range(4)]
                     pairs_.append(in_window_pairs(f[1], f[3], wl_radius) + in_window_pairs(f[2], f[0], wl_radius))
                 sad_wave_instr = float(np.mean(pairs_)) * 8 / 64 * S
-                peak = 1024 * 2.4e9 / 4.86
+                peak = 5.26e11
                 valu = {"unit": "v_sad_u8 wave-instructions/s", "achieved": sad_wave_instr / sec, "peak_measured": peak,
-                        "frac": sad_wave_instr / sec / peak, "in_window_pairs_per_stereo_pair": float(np.mean(pairs_))}
+                        "frac": sad_wave_instr / sec / peak, "in_window_pairs_per_stereo_pair": float(np.mean(pairs_)),
+                        "note": "compulsory SADs of the two flow passes only (the speculative search executes ~1.4x as many; "
+                                "pairs outside a query's window count as overhead, not as work)"}
+                if dom in prof_excl:
+                    valu["frac_exclusive"] = sad_wave_instr / (prof_excl[dom]["us_per_launch"] * 1e-6) / peak
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": S * B_pair, "us_per_launch": prof[dom]["us_per_launch"],
+                        "us_per_launch_is": "overlapped with the other internal stream (as in the timed region)",
+                        "binding_resource": "VALU issue of v_sad_u8 (half-rate instruction), not HBM",
                         "valu_sad": valu,
-                        "note": "integer SAD search: v_sad_u8 issue-bound, not HBM-bound (DESIGN.md)"}
+                        "note": "integer SAD search: v_sad_u8 issue-bound, not HBM-bound (DESIGN.md section 4)"}
+            if dom in prof_excl:
+                ex = prof_excl[dom]["us_per_launch"] * 1e-6
+                roofline["exclusive"] = {"us_per_launch": prof_excl[dom]["us_per_launch"], "achieved": S * B_pair / ex / 1e9,
+                                         "frac": S * B_pair / ex / 1e9 / HBM_PEAK_GBS,
+                                         "note": "the same kernel with every kernel of the step on one stream (VH_SERIAL=1)"}
         out = {
             "metric": METRIC if args.workload == "kitti" else f"stereo frame-pairs/sec (detect+match), {W}x{H}; matches bit-exact",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -326,11 +371,22 @@ def main():
                        "device_mib_per_stream": round(grp.deviceBytes() / S / 2**20, 2)},
             "roofline": roofline,
             "kernels_us_per_launch": {n_: round(v["us_per_launch"], 2) for n_, v in prof.items()},
+            "kernels_us_per_launch_exclusive": {n_: round(v["us_per_launch"], 2) for n_, v in prof_excl.items()},
+            "parity_scope": "primitives (computeFeatures, createIndexVector, findMatch, flow matching) pinned to the reference; "
+                            "stereo/quad composition per SURVEY A.7 (absent from the reference: unpinned)",
         }
         if not args.no_cpu:
             ob = entry.load_oracle()
             rate, n_pairs, secs, results = cpu_baseline(ob, frames_np, dims, args.cpu_seconds, wl["params"])
+            calib = None
+            try:
+                calib = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")))["port_over_reference_sse"]
+            except Exception:
+                pass
             out["cpu_baseline"] = {"value": rate, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "port_over_reference_sse": calib,
+                                   "port_over_reference_sse_source": "profiles/r02_cpu_calibration.json (tools/calibrate_cpu_baseline.py: the "
+                                                                      "reference's SSE build and this port on one core of the build container, cfg-1)",
                                    "sample": f"{n_pairs} consecutive stereo pairs of stream 0 (detect 2 images + quad match each), "
                                              f"{secs:.1f} s, oracle/viso_oracle.c single thread"}
             nthr = max(1, min(len(os.sched_getaffinity(0)), S, 16))  # 16 = the host-core share of one GPU on this pool

@@ -42,6 +42,7 @@ ABI_SYMBOLS = (
     "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_clear_stream", "vh_group_stream_wait_images", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
+    "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion",
 )
 
 
@@ -63,6 +64,21 @@ class Params(C.Structure):
                 raise AttributeError(k)
             setattr(p, k, v)
         return p
+
+
+class EgoParams(C.Structure):
+    """VisualOdometryStereo::parameters + calibration (reference src/viso_stereo.h:31-43, src/viso.h:41-50)."""
+    _fields_ = [("ransac_iters", C.c_int32), ("reweighting", C.c_int32), ("inlier_threshold", C.c_double),
+                ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double), ("base", C.c_double)]
+
+    @classmethod
+    def default(cls, **kw):
+        e = cls(ransac_iters=200, reweighting=1, inlier_threshold=2.0, f=1.0, cu=0.0, cv=0.0, base=1.0)
+        for k, v in kw.items():
+            if not hasattr(e, k):
+                raise AttributeError(k)
+            setattr(e, k, v)
+        return e
 
 
 #: Matcher::p_match (reference src/matcher.h:89-104), 48 bytes
@@ -129,6 +145,8 @@ def _lib():
             "vh_group_stream_wait_images": [vp, vp],
             "vh_group_profile_enable": [vp, i32], "vh_group_profile_read": [vp, C.c_char_p, vp, vp],
             "vh_group_profile_reset": [vp],
+            "vh_estimate_motion_stereo": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+            "vh_group_estimate_motion": [vp, vp, vp, vp, vp, vp],
         }
         for name, args in sig.items():
             fn = getattr(lib, name)
@@ -390,6 +408,15 @@ class StreamGroup:
         """Make `hip_stream` wait (device side) until the last pushBackDevice's images were consumed."""
         _check(_lib().vh_group_stream_wait_images(self._h, C.c_void_p(int(hip_stream))), "vh_group_stream_wait_images")
 
+    def estimateMotion(self, ego: "EgoParams", rand3):
+        """VisualOdometryStereo::estimateMotion (reference src/viso_stereo.cpp:54-157) on every stream's
+        device-resident quad matches; rand3 [S, ransac_iters, 3] int32 rand() values -> (tr [S,6], ok [S], n_inliers [S])."""
+        rand3 = np.ascontiguousarray(rand3, np.int32)
+        assert rand3.shape == (self.S, ego.ransac_iters, 3)
+        tr = np.zeros((self.S, 6), np.float64); ok = np.zeros(self.S, np.int32); ninl = np.zeros(self.S, np.int32)
+        _check(_lib().vh_group_estimate_motion(self._h, C.byref(ego), _ptr(rand3), _ptr(tr), _ptr(ok), _ptr(ninl)), "vh_group_estimate_motion")
+        return tr, ok.astype(bool), ninl
+
     def profileEnable(self, on: bool = True):
         _check(_lib().vh_group_profile_enable(self._h, 1 if on else 0), "vh_group_profile_enable")
 
@@ -468,6 +495,24 @@ def match_all_prior(param: Params, dims, m1, m2, u_: float, v_: float, flow: boo
     _check(_lib().vh_match_all_prior(C.byref(param), device, _dims(dims), _ptr(m1), n1, _ptr(m2), n2,
                                      1 if flow else 0, float(u_), float(v_), _ptr(best)), "vh_match_all_prior")
     return best[:n1]
+
+
+def estimate_motion_stereo(ego: EgoParams, match_lists, rand3, device: int = 0):
+    """VisualOdometryStereo::estimateMotion (reference src/viso_stereo.cpp:54-157), batched over
+    `match_lists` (a list of p_match arrays); rand3 [n_sets, ransac_iters, 3] int32 rand() values.
+    -> (tr [n,6], ok [n] bool, [inlier index arrays])."""
+    lists = [np.ascontiguousarray(m, dtype=P_MATCH_DTYPE) for m in match_lists]
+    n = len(lists)
+    offsets = np.zeros(n + 1, np.int32)
+    offsets[1:] = np.cumsum([len(m) for m in lists])
+    pm = np.concatenate(lists) if offsets[-1] else np.zeros(0, P_MATCH_DTYPE)
+    rand3 = np.ascontiguousarray(rand3, np.int32)
+    assert rand3.shape == (n, ego.ransac_iters, 3)
+    tr = np.zeros((n, 6), np.float64); ok = np.zeros(n, np.int32); ninl = np.zeros(n, np.int32)
+    inl = np.zeros(max(int(offsets[-1]), 1), np.int32)
+    _check(_lib().vh_estimate_motion_stereo(C.byref(ego), device, n, _ptr(pm), _ptr(offsets), _ptr(rand3), _ptr(tr), _ptr(ok),
+                                            _ptr(ninl), _ptr(inl)), "vh_estimate_motion_stereo")
+    return tr, ok.astype(bool), [inl[offsets[s]:offsets[s] + ninl[s]].copy() for s in range(n)]
 
 
 def remove_outliers(pm) -> np.ndarray:

@@ -624,6 +624,33 @@ struct Group {
     return failed ? VH_ERR_INVALID_ARG : VH_OK;
   }
 
+  // VisualOdometryStereo::estimateMotion on the device-resident quad match lists of every stream
+  int32_t estimate_motion(const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok, int32_t *ninl) {
+    if (!e || !rand3 || !tr || !ok || !ninl || e->ransac_iters < 1) return VH_ERR_INVALID_ARG;
+    if (!allocated || last_method != VH_METHOD_QUAD) return VH_ERR_STATE;
+    const size_t nr = (size_t)S * e->ransac_iters * 3;
+    int32_t *d_rand = nullptr, *d_ok = nullptr;
+    double *d_xyz = nullptr, *d_tr = nullptr;
+    // scratch of this call only (hipMalloc/hipFree: a few per frame; the matching itself never allocates)
+    VH_HIP(hipMalloc((void **)&d_rand, sizeof(int32_t) * nr));
+    hipError_t er = hipMalloc((void **)&d_xyz, sizeof(double) * (size_t)S * mcap * 4);
+    if (er == hipSuccess) er = hipMalloc((void **)&d_tr, sizeof(double) * 6 * (size_t)S);
+    if (er == hipSuccess) er = hipMalloc((void **)&d_ok, sizeof(int32_t) * 2 * (size_t)S);
+    if (er == hipSuccess) er = hipMemcpyAsync(d_rand, rand3, sizeof(int32_t) * nr, hipMemcpyHostToDevice, post_stream);
+    if (er == hipSuccess) {
+      vh_launch_ego(*e, S, (const vh_p_match *)d_matches, mcap, nullptr, d_match_count, mcap, d_rand, d_xyz, mcap, d_tr, d_ok, d_ok + S,
+                    nullptr, 0, post_stream);
+      er = hipGetLastError();
+    }
+    if (er == hipSuccess) er = hipMemcpyAsync(tr, d_tr, sizeof(double) * 6 * (size_t)S, hipMemcpyDeviceToHost, post_stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(ok, d_ok, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(ninl, d_ok + S, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(post_stream);
+    (void)hipFree(d_rand); (void)hipFree(d_xyz); (void)hipFree(d_tr); (void)hipFree(d_ok);
+    if (er != hipSuccess) { t_last_error = hipGetErrorString(er); return VH_ERR_HIP; }
+    return VH_OK;
+  }
+
   // Load caller-supplied feature records into a role's set and index it.
   int32_t load_features(int32_t role, const int32_t *m, int32_t n) {
     if (n < 0 || (n > 0 && !m)) return VH_ERR_INVALID_ARG;
@@ -963,6 +990,59 @@ int32_t vh_synchronize(vh_matcher *m) { return vh_group_synchronize((vh_group *)
 int32_t vh_set_stream(vh_matcher *m, void *hip_stream) { return vh_group_set_stream((vh_group *)m, hip_stream); }
 int32_t vh_clear_stream(vh_matcher *m) { return vh_group_clear_stream((vh_group *)m); }
 int32_t vh_stream_wait_images(vh_matcher *m, void *hip_stream) { return vh_group_stream_wait_images((vh_group *)m, hip_stream); }
+
+// ---- stereo egomotion ------------------------------------------
+void vh_default_ego_params(vh_ego_params *e) {
+  if (!e) return;
+  memset(e, 0, sizeof(*e));
+  e->ransac_iters = 200; e->reweighting = 1; e->inlier_threshold = 2.0;  // src/viso_stereo.h:39-41
+  e->f = 1; e->cu = 0; e->cv = 0; e->base = 1;                            // src/viso.h:46-48, src/viso_stereo.h:38
+}
+int32_t vh_group_estimate_motion(vh_group *g, const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok,
+                                 int32_t *n_inliers) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->estimate_motion(e, rand3, tr, ok, n_inliers);
+}
+int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_t n_sets, const vh_p_match *pm,
+                                  const int32_t *offsets, const int32_t *rand3, double *tr, int32_t *ok,
+                                  int32_t *n_inliers, int32_t *inliers) {
+  if (!e || n_sets < 1 || !offsets || !rand3 || !tr || !ok || !n_inliers || e->ransac_iters < 1) return VH_ERR_INVALID_ARG;
+  int64_t nmax = 0;
+  for (int32_t s = 0; s < n_sets; s++) {
+    if (offsets[s + 1] < offsets[s]) return VH_ERR_INVALID_ARG;
+    nmax = std::max<int64_t>(nmax, offsets[s + 1] - offsets[s]);
+  }
+  const int64_t total = offsets[n_sets];
+  if (total > 0 && !pm) return VH_ERR_INVALID_ARG;
+  const int32_t rc = select_device(device);
+  if (rc) return rc;
+  const size_t nr = (size_t)n_sets * e->ransac_iters * 3;
+  uint8_t *d = nullptr;
+  // one allocation: matches | offsets | rand3 | ok,ninl | inliers | tr | xyz+flags
+  const size_t b_pm = sizeof(vh_p_match) * (size_t)std::max<int64_t>(total, 1), b_off = sizeof(int32_t) * ((size_t)n_sets + 1);
+  const size_t b_r = sizeof(int32_t) * nr, b_ok = sizeof(int32_t) * 2 * (size_t)n_sets, b_inl = sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1);
+  const size_t b_tr = sizeof(double) * 6 * (size_t)n_sets, b_xyz = sizeof(double) * 4 * (size_t)n_sets * (size_t)std::max<int64_t>(nmax, 1);
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t o_off = up(b_pm), o_r = o_off + up(b_off), o_ok = o_r + up(b_r), o_inl = o_ok + up(b_ok), o_tr = o_inl + up(b_inl), o_xyz = o_tr + up(b_tr);
+  VH_HIP(hipMalloc((void **)&d, o_xyz + b_xyz));
+  hipError_t er = hipSuccess;
+  if (total) er = hipMemcpy(d, pm, sizeof(vh_p_match) * (size_t)total, hipMemcpyHostToDevice);
+  if (er == hipSuccess) er = hipMemcpy(d + o_off, offsets, b_off, hipMemcpyHostToDevice);
+  if (er == hipSuccess) er = hipMemcpy(d + o_r, rand3, b_r, hipMemcpyHostToDevice);
+  if (er == hipSuccess) {
+    vh_launch_ego(*e, n_sets, (const vh_p_match *)d, 0, (const int32_t *)(d + o_off), nullptr, 0, (const int32_t *)(d + o_r),
+                  (double *)(d + o_xyz), std::max<int64_t>(nmax, 1), (double *)(d + o_tr), (int32_t *)(d + o_ok), (int32_t *)(d + o_ok) + n_sets,
+                  (int32_t *)(d + o_inl), 0, nullptr);
+    er = hipDeviceSynchronize();
+  }
+  if (er == hipSuccess) er = hipMemcpy(tr, d + o_tr, b_tr, hipMemcpyDeviceToHost);
+  if (er == hipSuccess) er = hipMemcpy(ok, d + o_ok, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
+  if (er == hipSuccess) er = hipMemcpy(n_inliers, d + o_ok + sizeof(int32_t) * (size_t)n_sets, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
+  if (er == hipSuccess && inliers && total) er = hipMemcpy(inliers, d + o_inl, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (er != hipSuccess) { t_last_error = hipGetErrorString(er); return VH_ERR_HIP; }
+  return VH_OK;
+}
 
 // ---- stateless primitives ----------------------------------------------------
 int32_t vh_filters(int32_t device, const uint8_t *I, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,

@@ -162,4 +162,10 @@ void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t metho
                             void *matches, int32_t mcap, int32_t *match_count, int32_t *overflow,
                             const int32_t *mchunk, hipStream_t st);
 
+struct vh_ego_params;
+struct vh_p_match;
+void vh_launch_ego(const vh_ego_params &e, int32_t n_sets, const vh_p_match *pm, int64_t pm_stride, const int32_t *offsets,
+                   const int32_t *counts, int32_t count_cap, const int32_t *rand3, double *xyz, int64_t xyz_stride, double *tr,
+                   int32_t *ok, int32_t *ninl, int32_t *inl, int64_t inl_stride, hipStream_t st);
+
 #endif

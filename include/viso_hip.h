@@ -276,6 +276,42 @@ int32_t vh_group_set_stream(vh_group *g, void *hip_stream);
 int32_t vh_group_clear_stream(vh_group *g);
 int32_t vh_group_stream_wait_images(vh_group *g, void *hip_stream);
 
+/* ---- stereo egomotion ------------------------------------- */
+
+/* VisualOdometryStereo::parameters and the calibration it reads
+ * (src/viso_stereo.h:31-43, src/viso.h:41-50). */
+typedef struct vh_ego_params {
+  int32_t ransac_iters;     /* number of RANSAC iterations (200) */
+  int32_t reweighting;      /* 1 = lower border weights (src/viso_stereo.cpp:280-282) */
+  double inlier_threshold;  /* reprojection error bound in pixels (2.0) */
+  double f, cu, cv, base;   /* focal length, principal point (pixels), baseline (meters) */
+} vh_ego_params;
+/* VisualOdometryStereo::parameters() defaults; f = 1, cu = cv = 0, base = 1 as VisualOdometry::calibration(). */
+void vh_default_ego_params(vh_ego_params *e);
+
+/* VisualOdometryStereo::estimateMotion (src/viso_stereo.cpp:54-157) for n_sets independent
+ * match lists in one launch (one workgroup per list; RANSAC hypotheses in parallel, double
+ * precision): pm = the lists back to back, list s = pm[offsets[s] .. offsets[s+1]).
+ * rand3[n_sets][ransac_iters][3] = the values rand() returns while
+ * VisualOdometry::getRandomSample(N,3) draws each hypothesis' sample (src/viso.cpp:86-106;
+ * the reference seeds srand(0) in its constructor, src/viso.cpp:35) -- the caller owns the
+ * random stream, so the result is a function of the inputs.
+ * Outputs per list: tr[6] = (rx,ry,rz,tx,ty,tz) and ok = 1, or ok = 0 (and tr = 0) where the
+ * reference returns an empty vector (fewer than 6 matches / inliers, refinement not
+ * converged); n_inliers and, if inliers != NULL, the ascending inlier indices of the best
+ * hypothesis at inliers[offsets[s] ..] (VisualOdometry::getInlierIndices).
+ * Each hypothesis follows the reference's operation order exactly; the refinement sums the
+ * normal equations in parallel, so tr agrees with the reference to rounding (1e-9 relative
+ * is what tests/ assert), the inlier sets exactly. */
+int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_t n_sets, const vh_p_match *pm,
+                                  const int32_t *offsets, const int32_t *rand3, double *tr, int32_t *ok,
+                                  int32_t *n_inliers, int32_t *inliers);
+/* The same on the device-resident match lists of the group's last vh_group_match_features
+ * (flow matches carry no disparity: VH_METHOD_QUAD only, VH_ERR_STATE otherwise): nothing
+ * but rand3 [S][ransac_iters][3] goes up and S x (tr, ok, n_inliers) comes back. */
+int32_t vh_group_estimate_motion(vh_group *g, const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok,
+                                 int32_t *n_inliers);
+
 /* Kernel timing (HIP events recorded on the group's stream around every
  * kernel launch while enabled).  vh_group_profile_read returns the
  * accumulated milliseconds and launch count of kernel `name`

@@ -39,6 +39,30 @@ class Params(C.Structure):
         return p
 
 
+class EgoParams(C.Structure):
+    """VisualOdometryStereo::parameters + calibration (reference src/viso_stereo.h:31-43, src/viso.h:41-50)."""
+    _fields_ = [("ransac_iters", C.c_int32), ("reweighting", C.c_int32), ("inlier_threshold", C.c_double),
+                ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double), ("base", C.c_double)]
+
+    @classmethod
+    def default(cls, **kw):
+        e = cls(ransac_iters=200, reweighting=1, inlier_threshold=2.0, f=1.0, cu=0.0, cv=0.0, base=1.0)
+        for k, v in kw.items():
+            if not hasattr(e, k):
+                raise AttributeError(k)
+            setattr(e, k, v)
+        return e
+
+
+def glibc_rand_after_srand0(count: int) -> np.ndarray:
+    """The first `count` values of rand() after srand(0): what the reference's
+    VisualOdometry constructor seeds (src/viso.cpp:35) and getRandomSample consumes."""
+    libc = C.CDLL("libc.so.6")
+    libc.srand(0)
+    libc.rand.restype = C.c_int
+    return np.array([libc.rand() for _ in range(count)], np.int32)
+
+
 P_MATCH_DTYPE = np.dtype([
     ("u1p", "<f4"), ("v1p", "<f4"), ("i1p", "<i4"),
     ("u2p", "<f4"), ("v2p", "<f4"), ("i2p", "<i4"),
@@ -194,6 +218,25 @@ class Oracle:
         return pm[:n].copy(), depth.value
 
 
+    # ---- stereo egomotion -------------------------------------------------
+    def draw_samples(self, n_matches: int, iters: int, rand_values=None) -> np.ndarray:
+        """VisualOdometry::getRandomSample(N,3) x iters (src/viso.cpp:86-106) -> [iters,3] int32;
+        rand_values defaults to glibc's rand() sequence after srand(0)."""
+        r = glibc_rand_after_srand0(3 * iters) if rand_values is None else np.ascontiguousarray(rand_values, np.int32)
+        out = np.zeros((iters, 3), np.int32)
+        self.lib.vo_draw_samples(C.c_int32(n_matches), C.c_int32(iters), _ptr(r), _ptr(out))
+        return out
+
+    def estimate_motion_stereo(self, ego, pm, samples):
+        """VisualOdometryStereo::estimateMotion (src/viso_stereo.cpp:54-157) -> (ok, tr[6], inlier indices)."""
+        pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE)
+        samples = np.ascontiguousarray(samples, np.int32)
+        tr = np.zeros(6, np.float64); inl = np.zeros(max(len(pm), 1), np.int32); n = C.c_int32(0)
+        self.lib.vo_estimate_motion_stereo.restype = C.c_int32
+        ok = self.lib.vo_estimate_motion_stereo(C.byref(ego), _ptr(pm), C.c_int32(len(pm)), _ptr(samples), _ptr(tr), _ptr(inl), C.byref(n))
+        return bool(ok), tr, inl[:n.value].copy()
+
+
 class Reference:
     """The reference's own CPU/SSE code (oracle/_ref/libviso_ref.so)."""
 
@@ -285,3 +328,11 @@ class Reference:
         n = self.lib.ref_remove_outliers(_ptr(pm), C.c_int32(len(pm)))
         assert n >= 0, n
         return pm[:n].copy()
+
+    def estimate_motion_stereo(self, ego, pm):
+        """The reference's VisualOdometryStereo::estimateMotion on a fresh object (srand(0))."""
+        pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE)
+        tr = np.zeros(6, np.float64); inl = np.zeros(max(len(pm), 1), np.int32); n = C.c_int32(0)
+        self.lib.ref_estimate_motion_stereo.restype = C.c_int32
+        ok = self.lib.ref_estimate_motion_stereo(C.byref(ego), _ptr(pm), C.c_int32(len(pm)), _ptr(tr), _ptr(inl), C.byref(n))
+        return bool(ok), tr, inl[:n.value].copy()

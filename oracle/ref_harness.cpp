@@ -30,6 +30,7 @@
  * of THIS translation unit, straight from the read-only mount (-I$(REF)/src). */
 #define private public
 #include "matcher.cpp"
+#include "viso_stereo.h"   /* estimateMotion is private (src/viso_stereo.h:75) */
 #undef private
 #include "filter.h"
 
@@ -234,5 +235,28 @@ int32_t ref_delaunay(const float *xy, int32_t n, int32_t *tri, int32_t cap) {
 
 int32_t ref_sizeof_p_match(void) { return (int32_t)sizeof(Matcher::p_match); }
 int32_t ref_point_l(void) { return POINT_L; }
+
+
+/* VisualOdometryStereo::estimateMotion (src/viso_stereo.cpp:54-157) on
+ * caller-supplied matches, with a freshly constructed object (srand(0) in the
+ * constructor, src/viso.cpp:35, so the samples are rand()'s first 3*ransac_iters values).
+ * ego: {int32 ransac_iters, int32 reweighting, double inlier_threshold, f, cu, cv, base}.
+ * Returns 1/0 (success / empty result); tr[6], inliers (capacity n), *n_inliers. */
+struct HEgo { int32_t ransac_iters, reweighting; double inlier_threshold, f, cu, cv, base; };
+int32_t ref_estimate_motion_stereo(const void *ego, const void *pm, int32_t n, double *tr, int32_t *inliers, int32_t *n_inliers) {
+  const HEgo *e = (const HEgo *)ego;
+  VisualOdometryStereo::parameters param;
+  param.ransac_iters = e->ransac_iters; param.reweighting = e->reweighting != 0; param.inlier_threshold = e->inlier_threshold;
+  param.calib.f = e->f; param.calib.cu = e->cu; param.calib.cv = e->cv; param.base = e->base;
+  VisualOdometryStereo *vo = new VisualOdometryStereo(param);
+  std::vector<Matcher::p_match> v((const Matcher::p_match *)pm, (const Matcher::p_match *)pm + n);
+  std::vector<double> r = vo->estimateMotion(v);
+  std::vector<int32_t> inl = vo->getInlierIndices();
+  *n_inliers = (int32_t)inl.size();
+  for (size_t i = 0; i < inl.size(); i++) inliers[i] = inl[i];
+  for (int i = 0; i < 6; i++) tr[i] = r.size() == 6 ? r[i] : 0.0;
+  delete vo;
+  return r.size() == 6 ? 1 : 0;
+}
 
 }  // extern "C"

@@ -147,6 +147,22 @@ int32_t vo_remove_outliers(vo_p_match *pm, int32_t n, int32_t *max_depth);
 /* FNV-1a-64 over raw bytes. */
 uint64_t vo_fnv1a64(const void *data, uint64_t nbytes);
 
+/* ---- stereo egomotion (viso_egomotion.c) ------------------- */
+/* VisualOdometryStereo::parameters (src/viso_stereo.h:31-43) + the calibration it uses
+ * (src/viso.h:41-50, param.base). */
+typedef struct vo_ego_params {
+  int32_t ransac_iters;      /* 200 */
+  int32_t reweighting;       /* 1 */
+  double inlier_threshold;   /* 2.0 */
+  double f, cu, cv, base;
+} vo_ego_params;
+void vo_default_ego_params(vo_ego_params *e);
+/* [pinned] VisualOdometry::getRandomSample(N,3) x iters from successive rand() values r[3*iters] (src/viso.cpp:86-106). */
+void vo_draw_samples(int32_t N, int32_t iters, const int32_t *r, int32_t *samples);
+/* [pinned] VisualOdometryStereo::estimateMotion (src/viso_stereo.cpp:54-157) with given 3-point samples. */
+int32_t vo_estimate_motion_stereo(const vo_ego_params *e, const vo_p_match *pm, int32_t n, const int32_t *samples,
+                                  double tr[6], int32_t *inliers, int32_t *n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

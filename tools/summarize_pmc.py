@@ -6,20 +6,19 @@ import collections, csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "pmc_" + tag)
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "p*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         m = re.search(r"::(\w+)[<(]", r["Kernel_Name"])
         k = m.group(1) if m else r["Kernel_Name"]
-        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        cnt[k][r["Counter_Name"]] += 1
+        vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --pmc SQ_* on `VH_SERIAL=1 python bench.py --streams 128 --no-cpu` (exclusive kernels); "
-               "values are per launch, i.e. per step of 128 stereo pairs", "kernels": {}}
-for k in acc:
+               "values are the MEDIAN over the launches of a kernel, i.e. per full step of 128 stereo pairs "
+               "(the first match of a run, against an empty previous frame, is far cheaper and would drag a mean down)", "kernels": {}}
+for k in vals:
     if "rocclr" in k:
         continue
-    out["kernels"][k] = {c: acc[k][c] / cnt[k][c] for c in sorted(acc[k])}
+    out["kernels"][k] = {c: sorted(vals[k][c])[len(vals[k][c]) // 2] for c in sorted(vals[k])}
 json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc.json"), "w"), indent=1)
 for k, v in out["kernels"].items():
     g = lambda n: v.get(n, 0.0)

@@ -72,7 +72,9 @@ for k, v in per.items():
 json.dump(out, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
 dom = bench["roofline"]["kernel"]
-json.dump({"tag": tag, "streams": S, "kernel": dom, "hbm_bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"],
+import hashlib
+lib = os.path.join(ROOT, "hls-final-visual-odometry_amd", "libviso_hip.so")
+json.dump({"tag": tag, "streams": S, "kernel": dom, "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "hbm_bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"],
            "per_kernel": {k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items()}},
           open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print("value", bench["value"], "dominant", dom, "us(events)", bench["roofline"]["us_per_launch"], "us(rocprof)", avg_us.get(dom))
