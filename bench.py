@@ -46,6 +46,9 @@ KERNELS = ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill", "b
            "match", "chain", "emit_matches")
 
 
+NOISE = 0  # --noise: grey levels of uniform sensor noise added to every frame (context runs only)
+
+
 def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
     """[T][2][S][H][bpl] uint8: stream s follows sequence (seed 1 + (rank*S+s) % 8),
     phase-shifted so that no two streams of a rank see identical frames."""
@@ -56,7 +59,14 @@ def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
     def pair(seed, k):
         if (seed, k) not in cache:
             dx, dy = (5 * k) % 20, k % 20
-            cache[(seed, k)] = (pkg.synth.frame(W, H, dx, dy, 8, 1, seed), pkg.synth.frame(W, H, dx + 12, dy, 8, 1, seed))
+            pr = [pkg.synth.frame(W, H, dx, dy, 8, 1, seed), pkg.synth.frame(W, H, dx + 12, dy, 8, 1, seed)]
+            if NOISE:
+                rng = np.random.default_rng(seed * 1000 + k)
+                for i_ in range(2):
+                    im = np.clip(pr[i_].astype(np.int32) + rng.integers(-NOISE, NOISE + 1, pr[i_].shape), 0, 255).astype(np.uint8)
+                    im[:, W:] = 0
+                    pr[i_] = im
+            cache[(seed, k)] = tuple(pr)
         return cache[(seed, k)]
 
     for s, (gs, seed, phase) in enumerate(stream_assignment(rank, n_streams)):
@@ -198,12 +208,15 @@ def main():
                     help="independent camera streams per GPU, stepped together (0: the workload's default)")
     ap.add_argument("--frames", type=int, default=8, help="distinct frames per stream kept in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--noise", type=int, default=0, help="context runs: +-N grey levels of uniform noise on every frame "
+                    "(many more, mostly unmatched features; the driver's line is noise 0, the BASELINE workload)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
     args = ap.parse_args()
-    global W, H
+    global W, H, NOISE
+    NOISE = args.noise
     wl = WORKLOADS[args.workload]
     W, H = wl["W"], wl["H"]
     if args.streams <= 0:
@@ -296,6 +309,7 @@ def main():
             g2.matchFeatures(pkg.METHOD_QUAD)
         prof_excl = profiled(g2, min(args.steps, 12), 3)
         g2.close()
+    search_spec, search_redo = grp.searchStats()
     nf, nm = grp.getCounts()
     wl_radius = pkg.Params.default(**wl["params"]).match_radius
     last = (k - 1) % T
@@ -365,11 +379,14 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["label"],
+            "config": {"workload": wl["label"] + (f" + noise +-{NOISE}" if NOISE else ""),
                        "streams_per_gpu": S, "frames_in_hbm": T, "features_per_image": float(nfm.mean()),
                        "matches_per_pair": float(nm.mean()), "parallelism": f"{world}x independent stream groups",
                        "device_mib_per_stream": round(grp.deviceBytes() / S / 2**20, 2)},
             "roofline": roofline,
+            "search_loop": {"form": "speculative" if search_spec else "tested", "queries_searched_again": search_redo,
+                            "note": "chosen per launch from the share of queries whose best candidate over the walked region "
+                                    "lies outside their own window (DESIGN.md 4.1); results are identical either way"},
             "kernels_us_per_launch": {n_: round(v["us_per_launch"], 2) for n_, v in prof.items()},
             "kernels_us_per_launch_exclusive": {n_: round(v["us_per_launch"], 2) for n_, v in prof_excl.items()},
             "parity_scope": "primitives (computeFeatures, createIndexVector, findMatch, flow matching) pinned to the reference; "

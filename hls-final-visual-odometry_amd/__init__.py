@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_clear_stream", "vh_group_stream_wait_images", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
-    "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion",
+    "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion", "vh_group_search_stats",
 )
 
 
@@ -147,6 +147,7 @@ def _lib():
             "vh_group_profile_reset": [vp],
             "vh_estimate_motion_stereo": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
             "vh_group_estimate_motion": [vp, vp, vp, vp, vp, vp],
+            "vh_group_search_stats": [vp, vp, vp],
         }
         for name, args in sig.items():
             fn = getattr(lib, name)
@@ -416,6 +417,12 @@ class StreamGroup:
         tr = np.zeros((self.S, 6), np.float64); ok = np.zeros(self.S, np.int32); ninl = np.zeros(self.S, np.int32)
         _check(_lib().vh_group_estimate_motion(self._h, C.byref(ego), _ptr(rand3), _ptr(tr), _ptr(ok), _ptr(ninl)), "vh_group_estimate_motion")
         return tr, ok.astype(bool), ninl
+
+    def searchStats(self):
+        """-> (speculative loops in use?, last observed share of re-searched queries or -1)."""
+        sp = C.c_int32(0); rate = C.c_double(-1.0)
+        _check(_lib().vh_group_search_stats(self._h, C.byref(sp), C.byref(rate)), "vh_group_search_stats")
+        return bool(sp.value), rate.value
 
     def profileEnable(self, on: bool = True):
         _check(_lib().vh_group_profile_enable(self._h, 1 if on else 0), "vh_group_profile_enable")

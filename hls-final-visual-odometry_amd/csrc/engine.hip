@@ -56,7 +56,21 @@ struct Group {
   hipEvent_t ev_post[2] = {nullptr, nullptr};    // post-processing finished reading buffer b
   bool ev_post_valid[2] = {false, false};
   int64_t match_seq = 0;
-  int32_t *d_mchunk = nullptr;
+  int32_t *d_mchunk = nullptr;   // [S][cap/256] survivors per emission chunk, followed by the 2 statistics words of the launch
+  int32_t *d_redo = nullptr;     // [S] queries the speculative searches had to search again (reset by emit_matches)
+  // Loop policy of the searches (match()): speculative (no accept test in the loop, the winner
+  // verified, failures searched again) or tested.  The speculative loop is ~12 % faster when
+  // almost every query's best candidate lies inside its window (0.5 % re-searched on the
+  // benchmark frames) and slower once more than ~4 % fail (noisy images full of features
+  // without a partner).  Every launch reports (re-searched, searched) with a lag of one or two
+  // steps; above 3 % the tested loop takes over and the speculative one is probed every 16th
+  // launch, below 2 % it comes back.  Results never depend on the choice.
+  int32_t *h_stats = nullptr;    // page-locked [2][2]
+  hipEvent_t ev_stats[2] = {nullptr, nullptr};
+  bool stats_pending[2] = {false, false}, stats_was_spec[2] = {false, false};
+  int32_t stats_slot = 0, probe_countdown = 0, force_mode = -1;
+  bool spec_mode = true;
+  double last_redo_rate = -1;
   hipEvent_t ev_det[3] = {nullptr, nullptr, nullptr};   // slot fully detected + indexed
   hipEvent_t ev_read[3] = {nullptr, nullptr, nullptr};  // last match that read the slot
   bool ev_read_valid[3] = {false, false, false};
@@ -120,7 +134,8 @@ struct Group {
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_down) (void)hipEventDestroy(ev_down);
     if (down_stream) (void)hipStreamDestroy(down_stream);
-    for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); }
+    for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); if (ev_stats[k]) (void)hipEventDestroy(ev_stats[k]); }
+    if (h_stats) (void)hipHostFree(h_stats);
     if (post_stream && own_post) (void)hipStreamDestroy(post_stream);
     if (match_stream && !serial) (void)hipStreamDestroy(match_stream);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -141,7 +156,8 @@ struct Group {
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0; ev_down_valid = false;
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
-    d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr;
+    d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr; d_redo = nullptr;
+    stats_pending[0] = stats_pending[1] = false;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
     if (h_overflow) { (void)hipHostFree(h_overflow); h_overflow = nullptr; }
     allocated = false;
@@ -246,7 +262,8 @@ struct Group {
       if ((rc = dmalloc(&d_chain2[k], (size_t)S * cap, false))) return rc;
     }
     d_best = d_best2[0]; d_chain = d_chain2[0];
-    if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 255) / 256), true))) return rc;
+    if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 255) / 256) + 2, true))) return rc;
+    if ((rc = dmalloc(&d_redo, (size_t)S, true))) return rc;
     if ((rc = dmalloc((uint8_t **)&d_matches, (size_t)S * mcap * sizeof(vh_p_match), false))) return rc;
     if ((rc = dmalloc(&d_match_count, (size_t)S, true))) return rc;
     if ((rc = dmalloc(&d_overflow, (size_t)S, true))) return rc;
@@ -425,6 +442,22 @@ struct Group {
     return a;
   }
 
+  // speculative or tested search loops for the next launch (see the members above)
+  bool choose_loop() {
+    if (force_mode >= 0) return force_mode == 1;
+    for (int sl = 0; sl < 2; sl++) {
+      if (!stats_pending[sl] || hipEventQuery(ev_stats[sl]) != hipSuccess) continue;
+      stats_pending[sl] = false;
+      if (!stats_was_spec[sl] || h_stats[2 * sl + 1] <= 0) continue;  // the tested loop reports nothing
+      last_redo_rate = (double)h_stats[2 * sl] / (double)h_stats[2 * sl + 1];
+      if (spec_mode && last_redo_rate > 0.03) { spec_mode = false; probe_countdown = 16; }
+      else if (!spec_mode && last_redo_rate < 0.02) spec_mode = true;
+    }
+    if (spec_mode) return true;
+    if (--probe_countdown <= 0) { probe_countdown = 16; return true; }  // probe
+    return false;
+  }
+
   int32_t match(int32_t method) {
     if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
     if (!allocated || failed) return VH_ERR_STATE;
@@ -437,11 +470,13 @@ struct Group {
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_cur], 0));
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_prev], 0));
     if (ev_post_valid[buf]) VH_HIP(hipStreamWaitEvent(ms, ev_post[buf], 0));
-    { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], ms); }
+    const bool spec = choose_loop();
+    { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo, spec ? 1 : 0, ms); }
     VH_HIP(hipGetLastError());
     VH_HIP(hipEventRecord(ev_tables[buf], ms));
     VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
-    VH_HIP(hipMemsetAsync(d_mchunk, 0, sizeof(int32_t) * (size_t)S * ((cap + 255) / 256), ps));
+    const size_t n_mchunk = (size_t)S * ((cap + 255) / 256);
+    VH_HIP(hipMemsetAsync(d_mchunk, 0, sizeof(int32_t) * (n_mchunk + 2), ps));  // chunk counters + the launch's two statistics words
     if (method == VH_METHOD_FLOW) {
       if (!d_mask) {
         int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) return rc;
@@ -456,8 +491,14 @@ struct Group {
     { Scope sc(this, "chain", ps); vh_launch_chain(sets, a, method, d_best2[buf], d_chain2[buf], d_mask, epoch, d_mchunk, ps); }
     // a download of the previous step's lists may still be reading d_matches
     if (ev_down_valid) VH_HIP(hipStreamWaitEvent(ps, ev_down, 0));
-    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, ps); }
+    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, d_redo, d_mchunk + n_mchunk, ps); }
     VH_HIP(hipGetLastError());
+    {  // (re-searched, searched) of this launch -> page-locked memory, read by a later choose_loop()
+      const int32_t sl = stats_slot; stats_slot ^= 1;
+      VH_HIP(hipMemcpyAsync(h_stats + 2 * sl, d_mchunk + n_mchunk, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ps));
+      VH_HIP(hipEventRecord(ev_stats[sl], ps));
+      stats_pending[sl] = true; stats_was_spec[sl] = spec;
+    }
     VH_HIP(hipEventRecord(ev_post[buf], ps)); ev_post_valid[buf] = true;
     // both slots stay in use until this point of the post stream
     VH_HIP(hipEventRecord(ev_read[pair_cur], ps)); ev_read_valid[pair_cur] = true;
@@ -767,6 +808,11 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
     ok = hipEventCreateWithFlags(&gq->ev_det[k], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&gq->ev_read[k], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&gq->ev_user, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&gq->ev_stats[k], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&gq->h_stats, 4 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+  if (ok) memset(gq->h_stats, 0, 4 * sizeof(int32_t));
+  // VH_FLOW_TESTED=1 / =0: always the tested / always the speculative loops (default: adaptive)
+  if (const char *ft = getenv("VH_FLOW_TESTED")) gq->force_mode = atoi(ft) ? 0 : 1;
   for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&gq->ev_stage[k], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&gq->copy_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&gq->down_stream, hipStreamNonBlocking) == hipSuccess;
@@ -899,6 +945,12 @@ int32_t vh_group_stream_wait_images(vh_group *g, void *hip_stream) {
   if (!gq->allocated) return VH_OK;  // nothing pushed yet: nothing reads any image
   // the detection (and indexing) of the last pushed frame is the last reader of its images
   VH_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, gq->ev_det[gq->pair_cur], 0));
+  return VH_OK;
+}
+int32_t vh_group_search_stats(vh_group *g, int32_t *speculative, double *research_rate) {
+  Group *gq = (Group *)g; ENTER(gq);
+  if (speculative) *speculative = gq->force_mode >= 0 ? gq->force_mode : (gq->spec_mode ? 1 : 0);
+  if (research_rate) *research_rate = gq->last_redo_rate;
   return VH_OK;
 }
 int32_t vh_group_profile_enable(vh_group *g, int32_t on) {
@@ -1147,7 +1199,7 @@ int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3], 
   if ((rc = gq->load_features(VH_SET_1P, m2, n2))) return rc;
   VhMatchArgs a = gq->match_args(VH_METHOD_FLOW);
   a.npass = 1; a.pass[0] = {VH_SET_1C, VH_SET_1P, flow ? 1 : 0, 0};
-  vh_launch_match(gq->sets, a, gq->d_best, gq->stream);
+  vh_launch_match(gq->sets, a, gq->d_best, gq->d_redo, gq->force_mode == 0 ? 0 : 1, gq->stream);
   VH_HIP(hipGetLastError());
   if (n1) VH_HIP(hipMemcpyAsync(best, gq->d_best, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, gq->stream));
   VH_HIP(hipStreamSynchronize(gq->stream));

@@ -262,7 +262,7 @@ __device__ __forceinline__ int32_t key_mode_of(int32_t class_count, int32_t wide
 template <int Q, int P, int KM, bool SPEC>
 __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream,
                                           int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c,
-                                          int32_t pbase, int32_t pcnt, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
+                                          int32_t pbase, int32_t pcnt, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best, int32_t *__restrict__ redo_count) {
   constexpr int L = 64 / P;
   static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile (row-wise window reduction)");
   constexpr int TRIP = 2 * P;  // candidates per trip: two steps, joined by one v_min3_u32 per query
@@ -406,7 +406,7 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
 #pragma unroll
     for (int32_t qi = 0; qi < Q; qi++) {
       uint64_t todo = __ballot(redo[qi]);
-      if (todo) VH_STAT(7, __popcll(todo));
+      if (todo) { VH_STAT(7, __popcll(todo)); if (lane == 0) atomicAdd(redo_count, (int32_t)__popcll(todo)); }
       while (todo) {  // wave-uniform
         const int32_t fl = (int32_t)__builtin_ctzll(todo);
         todo &= todo - 1;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
 
 template <bool SPEC>
 __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
-                                          int32_t cset, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
+                                          int32_t cset, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best, int32_t *__restrict__ redo_count) {
   const int32_t ntile = s.tile_cnt[qset];
   for (int32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); tile < ntile;
        tile += gridDim.x * 4) {
@@ -455,9 +455,9 @@ __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a,
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
     const int32_t km = key_mode_of(pend - pbase, a.wide_keys);
-    if (km == KEY_HI16) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
-    else if (km == KEY_W19) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
-    else flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
+    if (km == KEY_HI16) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best, redo_count);
+    else if (km == KEY_W19) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best, redo_count);
+    else flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best, redo_count);
   }
 }
 
@@ -479,10 +479,10 @@ __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a,
 // order the rows are walked.  Round 1 used 64-query tiles with the test in the
 // loop: 100 evaluated candidates and 13 instructions per query and candidate
 // where ~15 candidates are inside the window; this form evaluates ~70 at 9.4.
-template <int Q, int P, int KM>
+template <int Q, int P, int KM, bool SPEC>
 __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
                                           int32_t cset, int32_t q0, int32_t q1, int32_t c, int32_t pbase, int32_t pcnt, uint4 *wD,
-                                          uint32_t *wU, int32_t *__restrict__ best) {
+                                          uint32_t *wU, uint32_t *wV, int32_t *__restrict__ best, int32_t *__restrict__ redo_count) {
   constexpr int L = 64 / P;
   static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile");
   constexpr int TRIP = 2 * P;
@@ -505,6 +505,8 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   int32_t qp[Q];
   typedef typename KeyT<KM>::type key_t;
   key_t best_key[Q];
+  us2 lo2[Q];
+  const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * a.disp_tol)};
   int32_t vmin = 0x7FFFFFFF, vmax = -1;
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
@@ -513,7 +515,8 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
     qp[qi] = qpos[valid[qi] ? q : q0];  // row order holds bin positions; the records are gathered from the bin-ordered arrays
     uv1[qi] = quv[qp[qi]];
     a0[qi] = qdesc[2 * (int64_t)qp[qi]]; a1[qi] = qdesc[2 * (int64_t)qp[qi] + 1];
-    const int32_t v1 = uv1[qi] >> 16;
+    const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
+    lo2[qi] = us2{(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};  // accept test as in flow_tile
     best_key[qi] = (key_t)~(key_t)0;
     vmin = min(vmin, v1); vmax = max(vmax, v1);
   }
@@ -527,24 +530,35 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
     const int32_t mcnt = min(64, r1 - rc);
     const int32_t cp = cpos[min(rc + lane, r1 - 1)];  // slots past the end repeat the last candidate: same key, harmless
     const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
+    uint32_t gu = 0;
+    if (!SPEC) gu = cuv[cp];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
     wD[lane] = g0; wD[64 + lane] = g1; wU[lane] = (uint32_t)(cp - pbase);
+    if (!SPEC) wV[lane] = gu;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
     const int32_t jend = (mcnt + TRIP - 1) & ~(TRIP - 1);
     VH_STAT(9, jend / TRIP);
     const uint4 *rd = wD + ph;
-    const uint32_t *ru = wU + ph;
+    const uint32_t *ru = wU + ph, *rv = wV + ph;
     for (int32_t j = 0; j < jend; j += TRIP) {
       const uint4 dA0 = rd[0], dA1 = rd[64], dB0 = rd[P], dB1 = rd[64 + P];
       const uint32_t sA = ru[0], sB = ru[P];
+      uint32_t uA = 0, uB = 0;
+      if (!SPEC) { uA = rv[0]; uB = rv[P]; }
 #pragma unroll
-      for (int32_t qi = 0; qi < Q; qi++)
-        best_key[qi] = min(min(sad_key<KM>(a0[qi], a1[qi], dA0, dA1, sA), sad_key<KM>(a0[qi], a1[qi], dB0, dB1, sB)), best_key[qi]);
-      rd += TRIP; ru += TRIP;
+      for (int32_t qi = 0; qi < Q; qi++) {
+        key_t kA = sad_key<KM>(a0[qi], a1[qi], dA0, dA1, sA), kB = sad_key<KM>(a0[qi], a1[qi], dB0, dB1, sB);
+        if (!SPEC) {  // the literal accept test (matcher.cpp:249) per pair
+          const us2 tA = as_us2(uA) - lo2[qi], tB = as_us2(uB) - lo2[qi];
+          kA = as_u32(tA) != as_u32(__builtin_elementwise_min(tA, span2)) ? (key_t)~(key_t)0 : kA;
+          kB = as_u32(tB) != as_u32(__builtin_elementwise_min(tB, span2)) ? (key_t)~(key_t)0 : kB;
+        }
+        best_key[qi] = min(min(kA, kB), best_key[qi]);
+      }
+      rd += TRIP; ru += TRIP; rv += TRIP;
     }
   }
-  // join the phases, test the winner against the query's own window, search again where it fails
-  const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * a.disp_tol)};
+  // join the phases; speculative form: test the winner against the query's own window, search again where it fails
   uint64_t kfin[Q];  // SAD << 32 | relative position, ~0: none
   bool redo[Q];
 #pragma unroll
@@ -554,18 +568,16 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
     for (int32_t d = L; d < 64; d <<= 1) k = min(k, shfl_xor_u64(k, d));
     kfin[qi] = k;
     redo[qi] = false;
-    if (valid[qi] && ph == 0 && k != ~0ull) {
-      const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
-      const us2 lo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
-      const us2 t = as_us2(cuv[pbase + min((int32_t)(uint32_t)k, pcnt - 1)]) - lo2;
+    if (SPEC && valid[qi] && ph == 0 && k != ~0ull) {
+      const us2 t = as_us2(cuv[pbase + min((int32_t)(uint32_t)k, pcnt - 1)]) - lo2[qi];
       const us2 m = __builtin_elementwise_min(t, span2);
       redo[qi] = as_u32(t) != as_u32(m);
     }
   }
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
-    uint64_t todo = __ballot(redo[qi]);
-    if (todo) VH_STAT(10, __popcll(todo));
+    uint64_t todo = SPEC ? __ballot(redo[qi]) : 0;
+    if (todo) { VH_STAT(10, __popcll(todo)); if (lane == 0) atomicAdd(redo_count, (int32_t)__popcll(todo)); }
     while (todo) {  // wave-uniform
       const int32_t fl = (int32_t)__builtin_ctzll(todo);
       todo &= todo - 1;
@@ -600,8 +612,10 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   }
 }
 
+template <bool SPEC>
 __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
-                                          int32_t cset, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best) {
+                                          int32_t cset, uint4 *wD, uint32_t *wU, uint32_t *wV, int32_t *__restrict__ best,
+                                          int32_t *__restrict__ redo_count) {
   const int32_t nrow = 4 * s.H;
   const int32_t *__restrict__ qrs = s.row_start + (int64_t)qset * (nrow + 1);
   // tile -> (class, query range): classes are contiguous in row order
@@ -622,9 +636,9 @@ __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a,
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
     const int32_t km = key_mode_of(pend - pbase, a.wide_keys);
-    if (km == KEY_HI16) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
-    else if (km == KEY_W19) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
-    else rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best);
+    if (km == KEY_HI16) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, best, redo_count);
+    else if (km == KEY_W19) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, best, redo_count);
+    else rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, best, redo_count);
   }
 }
 
@@ -637,16 +651,21 @@ __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a,
 // other (each is a pure function of its two feature sets).
 template <bool SPEC>
 __global__ void __launch_bounds__(256)
-match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best) {
+match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best, int32_t *__restrict__ redo) {
   __shared__ uint4 sDesc[4 * 128];   // per wave: 64 staged candidates, first | second descriptor half
   __shared__ uint32_t sAux[4 * 64];  // per wave: their u | v << 16 (tested flow loop) or key seeds (stereo)
+  __shared__ uint32_t sAux2[SPEC ? 1 : 4 * 64];  // per wave: u | v << 16 (tested stereo loop)
   const int32_t pass = blockIdx.y, stream = blockIdx.z;
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
   uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
   uint32_t *wU = sAux + (threadIdx.x >> 6) * 64;
-  if (a.pass[pass].flow) flow_pass<SPEC>(s, a, pass, stream, qset, cset, wD, wU, best);
-  else rows_pass(s, a, pass, stream, qset, cset, wD, wU, best);
+  uint32_t *wV = sAux2 + (SPEC ? 0 : (threadIdx.x >> 6) * 64);
+  // queries searched again by this stream's speculative passes: read by the host (with a lag) to
+  // choose between the speculative and the tested loops (engine.hip: match policy)
+  int32_t *redo_count = redo + stream;
+  if (a.pass[pass].flow) flow_pass<SPEC>(s, a, pass, stream, qset, cset, wD, wU, best, redo_count);
+  else rows_pass<SPEC>(s, a, pass, stream, qset, cset, wD, wU, wV, best, redo_count);
 }
 
 // ------------------------------------------------------------ match (prior term)
@@ -795,7 +814,8 @@ __global__ void flow_keep_kernel(VhSets s, VhMatchArgs a, int4 *__restrict__ cha
 __global__ void __launch_bounds__(256)
 emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restrict__ chain,
                     float *__restrict__ matches, int32_t mcap, int32_t *__restrict__ match_count,
-                    int32_t *__restrict__ overflow, const int32_t *__restrict__ mchunk, int32_t nchm) {
+                    int32_t *__restrict__ overflow, const int32_t *__restrict__ mchunk, int32_t nchm,
+                    int32_t *__restrict__ redo, int32_t *__restrict__ stats) {
   __shared__ int32_t sWave[4];
   __shared__ int32_t sBase;
   const int32_t chunk = blockIdx.x, stream = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -863,6 +883,13 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
       if (used && s.count[sets[r]] > s.cap) ov = 1;
     }
     overflow[stream] = ov;
+    // statistics of this launch for the host's loop policy: queries searched again / queries searched
+    int32_t nq = 0;
+#pragma unroll
+    for (int32_t k = 0; k < 4; k++) if (k < a.npass) nq += min(s.count[vh_role_set(a.S, a.pair_cur, stream, a.pass[k].qset)], s.cap);
+    atomicAdd(&stats[0], redo[stream]);
+    atomicAdd(&stats[1], nq);
+    redo[stream] = 0;
   }
 }
 
@@ -872,7 +899,7 @@ void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, dou
                            hipStream_t st) {
   hipLaunchKernelGGL(match_prior_kernel, dim3((s.cap + 127) / 128), dim3(128), 0, st, s, a, u_, v_, best);
 }
-void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st) {
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, hipStream_t st) {
   if (!a.npass) return;
   VhMatchArgs m = a;
   static const int wide = [] { const char *e = getenv("VH_FLOW_WIDE_KEYS"); return e ? atoi(e) : 0; }();
@@ -883,10 +910,8 @@ void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipSt
   static const int wgs = [] { const char *e = getenv("VH_FLOW_WGS"); return e ? atoi(e) : 0; }();
   const int32_t gx = wgs > 0 ? wgs : (s.max_tiles + 3) / 4;
   dim3 grid(gx, m.npass, a.S);
-  // VH_FLOW_TESTED=1: the flow loop with the per-pair accept tests instead of the speculative one (same results)
-  static const int tested = [] { const char *e = getenv("VH_FLOW_TESTED"); return e ? atoi(e) : 0; }();
-  if (tested) hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), 0, st, s, m, best);
-  else hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), 0, st, s, m, best);
+  if (speculative) hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), 0, st, s, m, best, redo);
+  else hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), 0, st, s, m, best, redo);
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st) {
@@ -898,8 +923,8 @@ void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, cons
 }
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
                             void *matches, int32_t mcap, int32_t *match_count, int32_t *overflow,
-                            const int32_t *mchunk, hipStream_t st) {
+                            const int32_t *mchunk, int32_t *redo, int32_t *stats, hipStream_t st) {
   const int32_t nchm = (s.cap + 255) / 256;
   hipLaunchKernelGGL(emit_matches_kernel, dim3(nchm, a.S), dim3(256), 0, st, s, a, method, chain,
-                     (float *)matches, mcap, match_count, overflow, mchunk, nchm);
+                     (float *)matches, mcap, match_count, overflow, mchunk, nchm, redo, stats);
 }

@@ -155,12 +155,12 @@ void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, i
 
 void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, double v_, int32_t *best,
                            hipStream_t st);
-void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, hipStream_t st);
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, hipStream_t st);
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st);
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
                             void *matches, int32_t mcap, int32_t *match_count, int32_t *overflow,
-                            const int32_t *mchunk, hipStream_t st);
+                            const int32_t *mchunk, int32_t *redo, int32_t *stats, hipStream_t st);
 
 struct vh_ego_params;
 struct vh_p_match;

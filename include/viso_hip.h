@@ -312,6 +312,13 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
 int32_t vh_group_estimate_motion(vh_group *g, const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok,
                                  int32_t *n_inliers);
 
+/* Which form of the search loops the group currently runs and the last observed share of
+ * queries the speculative form had to search again (-1 before the first report).  The
+ * searches are exact either way; the library switches between a speculative loop (no accept
+ * test per candidate, the winner verified afterwards) and the literal tested loop on that share
+ * (DESIGN.md section 4.1).  VH_FLOW_TESTED=1 / 0 in the environment pins the choice. */
+int32_t vh_group_search_stats(vh_group *g, int32_t *speculative, double *research_rate);
+
 /* Kernel timing (HIP events recorded on the group's stream around every
  * kernel launch while enabled).  vh_group_profile_read returns the
  * accumulated milliseconds and launch count of kernel `name`
