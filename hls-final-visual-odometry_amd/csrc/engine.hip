@@ -239,6 +239,7 @@ struct Group {
     sets.tile_span = (2 * p.match_radius >= dims[1]) ? sets.ubn * sets.vbn : sets.vbn;
     const size_t ns = 6 * (size_t)S;  // 3 ring slots x (left, right) per stream
     if ((rc = dmalloc(&sets.feat, ns * cap * 12, false))) return rc;
+    if ((rc = dmalloc(&sets.f_uv, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.s_uv, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.s_idx, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.s_desc, ns * cap * 8, false))) return rc;
@@ -259,7 +260,7 @@ struct Group {
     if ((rc = dmalloc(&d_chunk_count, 2 * (size_t)S * g.nchunks, true))) return rc;
     for (int k = 0; k < 2; k++) {
       if ((rc = dmalloc(&d_best2[k], 4 * (size_t)S * cap, false))) return rc;
-      if ((rc = dmalloc(&d_chain2[k], (size_t)S * cap, false))) return rc;
+      if ((rc = dmalloc(&d_chain2[k], 2 * (size_t)S * cap, false))) return rc;  // index tuple + coordinate tuple per driving feature
     }
     d_best = d_best2[0]; d_chain = d_chain2[0];
     if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 255) / 256) + 2, true))) return rc;

@@ -62,6 +62,7 @@ __global__ void bin_hist_kernel(VhSets s, int32_t set0) {
   const int32_t n = min(s.count[set], s.cap);
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int32_t *f = s.feat + ((int64_t)set * s.cap + i) * 12;
+    s.f_uv[(int64_t)set * s.cap + i] = (uint32_t)f[0] | ((uint32_t)f[1] << 16);  // caller-supplied features: emit_features did not write it
     atomicAdd(&s.hist[(int64_t)set * s.nbins + feature_bin(f, s)], 1);
     atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + f[3] * s.H + f[1]], 1);
   }

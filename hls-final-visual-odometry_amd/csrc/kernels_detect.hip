@@ -592,6 +592,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
       else word = plo | (phi << 16);
       const int32_t fi = base + fs[h];
       if (lives[h] && k < 12 && fi < cap) out[(int64_t)fi * 12 + k] = (int32_t)word;
+      if (lives[h] && k == 12 && fi < cap) s.f_uv[(int64_t)set * cap + fi] = (uint32_t)(u * g.scale) | ((uint32_t)(v * g.scale) << 16);
     }
   }
 }

@@ -743,47 +743,45 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
   const int32_t n1c = min(s.count[set1c], s.cap), n2c = min(s.count[set2c], s.cap);
   const int32_t *__restrict__ T = best + (int64_t)stream * 4 * s.cap;
   const int64_t cap = s.cap;
-  int4 *__restrict__ out = chain + (int64_t)stream * s.cap;
+  // coordinates in reference order, 4 B per feature (the 48-byte records would cost a 64-byte sector per look-up)
+  const uint32_t *__restrict__ uv1p = s.f_uv + (int64_t)set1p * cap, *__restrict__ uv2p = s.f_uv + (int64_t)set2p * cap;
+  const uint32_t *__restrict__ uv1c = s.f_uv + (int64_t)set1c * cap, *__restrict__ uv2c = s.f_uv + (int64_t)set2c * cap;
+  int4 *__restrict__ out = chain + 2 * (int64_t)stream * s.cap;
   const int32_t ndrive = (method == 2) ? n1p : n1c;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ndrive; i += gridDim.x * blockDim.x) {
-  if (method == 0) {
-    int4 r = make_int4(-1, -1, -2, -1);
-    if (n1p > 0) {
-      const int32_t i1p = T[0 * cap + i];
-      const int32_t i1c2 = T[1 * cap + i1p];
-      if (i1c2 == i) {
-        r = make_int4(i1p, -1, i, -1);
-        const int32_t *f = s.feat + ((int64_t)set1c * s.cap + i) * 12;
-        atomicMax(&mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]],
-                  (epoch << VH_MASK_IDX_BITS) | (((1u << VH_MASK_IDX_BITS) - 1u) - (uint32_t)i));
+    int4 r = make_int4(-1, -1, -2, -1), c = make_int4(0, 0, 0, 0);
+    if (method == 0) {
+      if (n1p > 0) {
+        const int32_t i1p = T[0 * cap + i];
+        const int32_t i1c2 = T[1 * cap + i1p];
+        if (i1c2 == i) {
+          r = make_int4(i1p, -1, i, -1);
+          c.x = (int32_t)uv1p[i1p]; c.z = (int32_t)uv1c[i];
+          atomicMax(&mask[(int64_t)stream * s.W * s.H + (int64_t)((uint32_t)c.z >> 16) * s.W + ((uint32_t)c.z & 0xFFFFu)],
+                    (epoch << VH_MASK_IDX_BITS) | (((1u << VH_MASK_IDX_BITS) - 1u) - (uint32_t)i));
+        }
+      }
+    } else if (method == 1) {
+      if (n2c > 0) {
+        const int32_t i2c = T[0 * cap + i];
+        const int32_t i1c2 = T[1 * cap + i2c];
+        c.z = (int32_t)uv1c[i]; c.w = (int32_t)uv2c[i2c];
+        if (i1c2 == i && ((uint32_t)c.z & 0xFFFFu) >= ((uint32_t)c.w & 0xFFFFu)) r = make_int4(-1, -1, i, i2c);
+      }
+    } else {
+      if (n2p > 0 && n1c > 0 && n2c > 0) {
+        const int32_t i2p = T[0 * cap + i];
+        const int32_t i2c = T[1 * cap + i2p];
+        const int32_t i1c = T[2 * cap + i2c];
+        const int32_t i1p2 = T[3 * cap + i1c];
+        c = make_int4((int32_t)uv1p[i], (int32_t)uv2p[i2p], (int32_t)uv1c[i1c], (int32_t)uv2c[i2c]);
+        const uint32_t u1p = (uint32_t)c.x & 0xFFFFu, u2p = (uint32_t)c.y & 0xFFFFu, u1c = (uint32_t)c.z & 0xFFFFu, u2c = (uint32_t)c.w & 0xFFFFu;
+        if (i1p2 == i && u1p >= u2p && u1c >= u2c) r = make_int4(i, i2p, i1c, i2c);
       }
     }
-    out[i] = r;
-  } else if (method == 1) {
-    int4 r = make_int4(-1, -1, -2, -1);
-    if (n2c > 0) {
-      const int32_t i2c = T[0 * cap + i];
-      const int32_t i1c2 = T[1 * cap + i2c];
-      const int32_t u1c = s.feat[((int64_t)set1c * s.cap + i) * 12], u2c = s.feat[((int64_t)set2c * s.cap + i2c) * 12];
-      if (i1c2 == i && u1c >= u2c) r = make_int4(-1, -1, i, i2c);
-    }
-    out[i] = r;
-    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 8));
-  } else {
-    int4 r = make_int4(-1, -1, -2, -1);
-    if (n2p > 0 && n1c > 0 && n2c > 0) {
-      const int32_t i2p = T[0 * cap + i];
-      const int32_t i2c = T[1 * cap + i2p];
-      const int32_t i1c = T[2 * cap + i2c];
-      const int32_t i1p2 = T[3 * cap + i1c];
-      const int32_t u1p = s.feat[((int64_t)set1p * s.cap + i) * 12], u2p = s.feat[((int64_t)set2p * s.cap + i2p) * 12];
-      const int32_t u1c = s.feat[((int64_t)set1c * s.cap + i1c) * 12], u2c = s.feat[((int64_t)set2c * s.cap + i2c) * 12];
-      if (i1p2 == i && u1p >= u2p && u1c >= u2c) r = make_int4(i, i2p, i1c, i2c);
-    }
-    out[i] = r;
-    count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 8));
+    out[2 * (int64_t)i] = r; out[2 * (int64_t)i + 1] = c;
+    if (method != 0) count_chunk(r.z >= 0, mchunk + stream * nchm + (i >> 8));
   }
-  }  // grid-stride loop
 }
 
 // ------------------------------------------------------------------ flow_keep
@@ -796,12 +794,13 @@ __global__ void flow_keep_kernel(VhSets s, VhMatchArgs a, int4 *__restrict__ cha
   const int32_t stream = blockIdx.y;
   const int32_t set1c = vh_role_set(a.S, a.pair_cur, stream, 2);
   const int32_t n1c = min(s.count[set1c], s.cap);
-  int4 *__restrict__ ch = chain + (int64_t)stream * s.cap;
+  int4 *__restrict__ ch = chain + 2 * (int64_t)stream * s.cap;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n1c; i += gridDim.x * blockDim.x) {
-    const int4 r = ch[i];
-    const int32_t *f = s.feat + ((int64_t)set1c * s.cap + i) * 12;
-    const bool win = r.z >= 0 && mask[(int64_t)stream * s.W * s.H + (int64_t)f[1] * s.W + f[0]] == ((epoch << VH_MASK_IDX_BITS) | (((1u << VH_MASK_IDX_BITS) - 1u) - (uint32_t)i));
-    if (r.z >= 0 && !win) ch[i].z = -2;
+    const int4 r = ch[2 * (int64_t)i];
+    const uint32_t uv = (uint32_t)ch[2 * (int64_t)i + 1].z;
+    const bool win = r.z >= 0 && mask[(int64_t)stream * s.W * s.H + (int64_t)(uv >> 16) * s.W + (uv & 0xFFFFu)] ==
+                                     ((epoch << VH_MASK_IDX_BITS) | (((1u << VH_MASK_IDX_BITS) - 1u) - (uint32_t)i));
+    if (r.z >= 0 && !win) ch[2 * (int64_t)i].z = -2;
     count_chunk(win, mchunk + stream * nchm + (i >> 8));
   }
 }
@@ -825,7 +824,7 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
   const int32_t drive = (method == 2) ? sets[0] : sets[2];
   const int32_t n = min(s.count[drive], s.cap);
   if (chunk * 256 >= n && chunk != nchm - 1) return;
-  const int4 *__restrict__ ch = chain + (int64_t)stream * s.cap;
+  const int4 *__restrict__ ch = chain + 2 * (int64_t)stream * s.cap;
   float *__restrict__ out = matches + (int64_t)stream * mcap * 12;
   // matches emitted by earlier chunks
   int32_t part = 0;
@@ -840,20 +839,20 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
   __syncthreads();
 
   const int32_t i = chunk * 256 + tid;
-  int4 r = make_int4(-1, -1, -2, -1);
-  if (i < n) r = ch[i];
+  int4 r = make_int4(-1, -1, -2, -1), c = make_int4(0, 0, 0, 0);
+  if (i < n) { r = ch[2 * (int64_t)i]; c = ch[2 * (int64_t)i + 1]; }
   const bool keep = r.z >= 0;
   uint32_t rec[12];
 #pragma unroll
   for (int32_t k = 0; k < 12; k++) rec[k] = (k % 3 == 2) ? 0xFFFFFFFFu : __float_as_uint(-1.0f);
   if (keep) {
     const int32_t idx[4] = {r.x, r.y, r.z, r.w};
+    const uint32_t uv[4] = {(uint32_t)c.x, (uint32_t)c.y, (uint32_t)c.z, (uint32_t)c.w};
 #pragma unroll
     for (int32_t k = 0; k < 4; k++) {
       if (idx[k] >= 0) {
-        const int32_t *f = s.feat + ((int64_t)sets[k] * s.cap + idx[k]) * 12;
-        rec[3 * k + 0] = __float_as_uint((float)f[0]);
-        rec[3 * k + 1] = __float_as_uint((float)f[1]);
+        rec[3 * k + 0] = __float_as_uint((float)(uv[k] & 0xFFFFu));
+        rec[3 * k + 1] = __float_as_uint((float)(uv[k] >> 16));
       }
       rec[3 * k + 2] = (uint32_t)idx[k];
     }

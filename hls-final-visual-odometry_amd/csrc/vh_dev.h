@@ -12,6 +12,7 @@
 //
 //   feat      [set][cap][12] int32   the reference's packed record
 //                                    {u,v,0,c,d1..d8} (src/matcher.cpp:663-671)
+//   f_uv      [set][cap]     uint32  u | v<<16, in reference order (compact copy of feat's first two words)
 //   s_uv      [set][cap]     uint32  u | v<<16, in *bin order*
 //   s_idx     [set][cap]     int32   original feature index of that position
 //   s_desc    [set][cap][8]  uint32  32-byte descriptor, in bin order
@@ -70,6 +71,7 @@ struct VhGeom {
 
 struct VhSets {
   int32_t *feat;
+  uint32_t *f_uv;      // [set][cap] u | v << 16 in reference (feature index) order: what the chains and the emission gather
   uint32_t *s_uv;
   int32_t *s_idx;
   uint32_t *s_desc;
@@ -156,6 +158,7 @@ void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, i
 void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, double v_, int32_t *best,
                            hipStream_t st);
 void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, hipStream_t st);
+// chain: [stream][cap][2] int4 = {i1p,i2p,i1c,i2c} (z = -2: no match), {uv1p,uv2p,uv1c,uv2c}
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st);
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
