@@ -448,13 +448,14 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const int32_t base = sBase;
   __syncthreads();
 
-  // phase A: each lane owns 4 consecutive blocks; the four 16-bit codes of a
+  // phase A: each lane owns VH_CHUNK/256 consecutive blocks; the four 16-bit codes of a
   // block are handled as two dwords so every extract is one 32-bit op
-  uint32_t clo[4], chi[4];
+  constexpr int BPL = VH_CHUNK / 256;  // consecutive blocks per lane
+  uint32_t clo[BPL], chi[BPL];
   int32_t mine = 0;
 #pragma unroll
-  for (int32_t k = 0; k < 4; k++) {
-    const int32_t blk = chunk * VH_CHUNK + tid * 4 + k;
+  for (int32_t k = 0; k < BPL; k++) {
+    const int32_t blk = chunk * VH_CHUNK + tid * BPL + k;
     uint2 c = make_uint2(~0u, ~0u);
     if (blk < g.nblocks) c = reinterpret_cast<const uint2*>(rec)[(int64_t)id * g.nblocks + blk];
     clo[k] = c.x;
@@ -472,11 +473,11 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     // position code = (row in block) << 6 | (column in block); block coordinates
     // advance incrementally (one division per lane, not one per block and code).
     // Appends are branch-free: an empty slot is written to the sink word.
-    const int32_t blk0 = chunk * VH_CHUNK + tid * 4;
+    const int32_t blk0 = chunk * VH_CHUNK + tid * BPL;
     int32_t by = blk0 / g.nbx, bx = blk0 - by * g.nbx;
     const uint32_t org = (uint32_t)(g.n + VH_MARGIN) * ((1u << 14) + 1u);
 #pragma unroll
-    for (int32_t k = 0; k < 4; k++) {
+    for (int32_t k = 0; k < BPL; k++) {
       const uint32_t pxy = org + (uint32_t)(bx * n1) + ((uint32_t)(by * n1) << 14);  // u | v<<14 of the block corner
 #pragma unroll
       for (int32_t q = 0; q < 4; q++) {
@@ -537,8 +538,11 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
         const uint32_t off0 = (uint32_t)((vs[h] + dy - 2) * g.bplm + (x0 & ~3));
 #pragma unroll
         for (int32_t r = 0; r < 5; r++) {
-          const uint8_t *pr = I + (off0 + (uint32_t)(r * g.bplm));
-          lo[h][r] = *(const uint32_t *)pr; hi[h][r] = *(const uint32_t *)(pr + 4);
+          // one 8-byte load per row segment (4-byte aligned: global memory takes it), not two dword loads:
+          // the kernel is bound by the number of scattered load instructions, not by their bytes
+          typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+          const u32x2a4 w2 = *(const u32x2a4 *)(I + (off0 + (uint32_t)(r * g.bplm)));
+          lo[h][r] = w2.x; hi[h][r] = w2.y;
         }
       }
     }

@@ -33,7 +33,9 @@
 #include <stdint.h>
 
 #define VH_MARGIN 7          // src/matcher.cpp:38
-#define VH_CHUNK 1024        // NMS blocks per emit workgroup
+#ifndef VH_CHUNK
+#define VH_CHUNK 1024        // NMS blocks per emit workgroup (a multiple of 256)
+#endif
 #define VH_WAVE 64
 // Flow search (kernels_match.hip): a wave is VH_FLOW_P phases of 64/VH_FLOW_P lanes, VH_FLOW_Q
 // queries per lane; the phases share one candidate stream.
