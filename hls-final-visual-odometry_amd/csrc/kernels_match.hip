@@ -43,6 +43,12 @@ extern "C" int32_t vh_debug_flow_stats(unsigned long long *out, int32_t reset) {
 #define VH_STAT(k, n) do { } while (0)
 #endif
 
+// register budget of match_kernel: at least this many waves per SIMD must fit (the loop hides its LDS and L2
+// round trips behind other waves; 99 registers / 4 waves measured 7 % slower than 68 / 7)
+#ifndef VH_MATCH_WAVES
+#define VH_MATCH_WAVES 7
+#endif
+
 namespace {
 
 __device__ __forceinline__ int32_t wave_min(int32_t v) {
@@ -356,18 +362,27 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
       const uint32_t *ru = wU + ph;
       uint32_t seedA = (uint32_t)(pc - pbase + ph), seedB = seedA + P;
       int32_t j = 0;
+      // one trip: candidates (j + ph) and (j + P + ph) at slot offset `o` of this phase's read pointers
+      auto trip = [&](auto test, int32_t o) {
+        const uint4 dA0 = rd[o], dA1 = rd[o + 64], dB0 = rd[o + P], dB1 = rd[o + 64 + P];
+        uint32_t uA = 0, uB = 0;
+        if (decltype(test)::value != 0) { uA = ru[o]; uB = ru[o + P]; }
+#pragma unroll
+        for (int32_t qi = 0; qi < Q; qi++) {
+          const key_t kA = make_key(test, qi, uA, dA0, dA1, seedA + (uint32_t)o), kB = make_key(test, qi, uB, dB0, dB1, seedB + (uint32_t)o);
+          best_key[qi] = min(min(kA, kB), best_key[qi]);
+        }
+      };
       auto run = [&](auto test, int32_t jstop) {
         if (jstop > j) VH_STAT(2 + decltype(test)::value, (jstop - j) / TRIP);
-        for (; j < jstop; j += TRIP) {
-          const uint4 dA0 = rd[0], dA1 = rd[64], dB0 = rd[P], dB1 = rd[64 + P];
-          uint32_t uA = 0, uB = 0;
-          if (decltype(test)::value != 0) { uA = ru[0]; uB = ru[P]; }
-#pragma unroll
-          for (int32_t qi = 0; qi < Q; qi++) {
-            const key_t kA = make_key(test, qi, uA, dA0, dA1, seedA), kB = make_key(test, qi, uB, dB0, dB1, seedB);
-            best_key[qi] = min(min(kA, kB), best_key[qi]);
-          }
-          rd += TRIP; ru += TRIP; seedA += TRIP; seedB += TRIP;
+        // two trips per loop iteration: the pointer and seed updates (and the loop control) once per 16 candidates
+        for (; j + 2 * TRIP <= jstop; j += 2 * TRIP) {
+          trip(test, 0); trip(test, TRIP);
+          rd += 2 * TRIP; ru += 2 * TRIP; seedA += 2 * TRIP; seedB += 2 * TRIP;
+        }
+        if (j < jstop) {
+          trip(test, 0);
+          j += TRIP; rd += TRIP; ru += TRIP; seedA += TRIP; seedB += TRIP;
         }
       };
       if (SPEC) {
@@ -650,7 +665,7 @@ __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a,
 // slots the stereo waves leave idle.  All passes of a method are independent of each
 // other (each is a pure function of its two feature sets).
 template <bool SPEC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VH_MATCH_WAVES, 8)))
 match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best, int32_t *__restrict__ redo) {
   __shared__ uint4 sDesc[4 * 128];   // per wave: 64 staged candidates, first | second descriptor half
   __shared__ uint32_t sAux[4 * 64];  // per wave: their u | v << 16 (tested flow loop) or key seeds (stereo)
