@@ -499,7 +499,20 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   // feature.  Kept out of the descriptor loop below: a returning atomic inside
   // it serialised one L2 round trip per loop trip.  createIndexVector's bin
   // (matcher.cpp:208-212) and the (class, v) row; the arbitrary arrival order of
-  // the slots is undone by bin_sort.
+  // the slots is undone by bin_sort.  The (class, v) row counts of the chunk --
+  // its blocks span only a few pixel rows -- are first added up in LDS and flushed
+  // with one global atomic per row that occurs (this phase is bound by the rate of
+  // L2 atomics: ~2 per feature before, ~1.15 now).
+  constexpr int ROWS_LDS = 64;
+  __shared__ int32_t sRow[4 * ROWS_LDS];
+  const int32_t blk_first = chunk * VH_CHUNK, blk_last = min(blk_first + VH_CHUNK, g.nblocks) - 1;
+  const int32_t v_first = ((blk_first / g.nbx) * n1 + g.n + VH_MARGIN) * g.scale;                      // smallest v a feature of this chunk can have
+  const int32_t v_span = ((blk_last / g.nbx) * n1 + g.n + VH_MARGIN + g.n) * g.scale + g.scale - v_first;  // ... and one past the largest, relative
+  const bool rows_in_lds = v_span <= ROWS_LDS;
+  if (rows_in_lds) {
+    for (int32_t k = tid; k < 4 * ROWS_LDS; k += 256) sRow[k] = 0;
+    __syncthreads();
+  }
   for (int32_t f = tid; f < total; f += 256) {
     const int32_t fi = base + f;
     if (fi >= cap) break;
@@ -510,7 +523,15 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     const int32_t b = (c * s.ubn + min(ubin, s.ubn - 1)) * s.vbn + min(vbin, s.vbn - 1);
     const int32_t slot = atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
     if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = fi;
-    atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], 1);
+    if (rows_in_lds) atomicAdd(&sRow[c * ROWS_LDS + (vv - v_first)], 1);
+    else atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], 1);
+  }
+  if (rows_in_lds) {
+    __syncthreads();
+    for (int32_t k = tid; k < 4 * ROWS_LDS; k += 256) {
+      const int32_t cnt = sRow[k], c = k / ROWS_LDS, vv = v_first + k % ROWS_LDS;
+      if (cnt) atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], cnt);
+    }
   }
 
   // phase B: 16 lanes per feature, lane k = sample point k; two features per lane
