@@ -170,6 +170,12 @@ struct Group {
     allocs.push_back(q);
     device_bytes += (int64_t)bytes;
     if (zero) VH_HIP(hipMemsetAsync(q, 0, bytes, stream));
+    else {
+      // VH_POISON=1 (test aid): fill every buffer that is not zero-initialised with 0xA5, so that a
+      // kernel consuming memory nobody wrote misbehaves the same way on every box
+      static const bool poison = [] { const char *e = getenv("VH_POISON"); return e && e[0] == '1'; }();
+      if (poison) VH_HIP(hipMemsetAsync(q, 0xA5, bytes, stream));
+    }
     *out = (T *)q;
     return VH_OK;
   }
@@ -1043,6 +1049,20 @@ int32_t vh_synchronize(vh_matcher *m) { return vh_group_synchronize((vh_group *)
 int32_t vh_set_stream(vh_matcher *m, void *hip_stream) { return vh_group_set_stream((vh_group *)m, hip_stream); }
 int32_t vh_clear_stream(vh_matcher *m) { return vh_group_clear_stream((vh_group *)m); }
 int32_t vh_stream_wait_images(vh_matcher *m, void *hip_stream) { return vh_group_stream_wait_images((vh_group *)m, hip_stream); }
+
+#ifdef VH_DEBUG_ROWS
+// debug build only: the (class, v) row index of one feature set
+int32_t vh_debug_rows(vh_matcher *m, int32_t which, int32_t *row_start, int32_t *r_pos, int32_t *bin_start) {
+  Group *gq = (Group *)m; ENTER(gq);
+  const int32_t set = vh_role_set(gq->S, gq->pairs(), 0, which);
+  const size_t nrow = 4 * (size_t)gq->dims[1];
+  VH_HIP(hipDeviceSynchronize());
+  VH_HIP(hipMemcpy(row_start, gq->sets.row_start + (size_t)set * (nrow + 1), sizeof(int32_t) * (nrow + 1), hipMemcpyDeviceToHost));
+  VH_HIP(hipMemcpy(r_pos, gq->sets.r_pos + (size_t)set * gq->cap, sizeof(int32_t) * gq->cap, hipMemcpyDeviceToHost));
+  VH_HIP(hipMemcpy(bin_start, gq->sets.bin_start + (size_t)set * (gq->sets.nbins + 1), sizeof(int32_t) * (gq->sets.nbins + 1), hipMemcpyDeviceToHost));
+  return gq->cap;
+}
+#endif
 
 // ---- stereo egomotion ------------------------------------------
 void vh_default_ego_params(vh_ego_params *e) {

@@ -175,10 +175,10 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
   const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
   const int32_t p0 = bs[bin], p1 = bs[bin + 1], L = p1 - p0;
   if (L <= 0) return;
-  // members of this bin, in arbitrary order: staged by emit_features (own
-  // features) or placed by bin_fill (caller-supplied features)
-  const int32_t *__restrict__ tmp = staged ? s.stage + ((int64_t)set * s.nbins + bin) * s.stage_cap - p0
-                                           : s.tmp_idx + (int64_t)set * s.cap;
+  // members of this bin, in arbitrary order: staged by emit_features (own features, with
+  // their rank in their (class, v) row) or placed by bin_fill (caller-supplied features)
+  const int2 *__restrict__ stg = s.stage + ((int64_t)set * s.nbins + bin) * s.stage_cap - p0;
+  const int32_t *__restrict__ tmp = s.tmp_idx + (int64_t)set * s.cap;
   const int32_t *__restrict__ feat = s.feat + (int64_t)set * s.cap * 12;
   int32_t *__restrict__ sidx = s.s_idx + (int64_t)set * s.cap;
   uint32_t *__restrict__ suv = s.s_uv + (int64_t)set * s.cap;
@@ -189,7 +189,11 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
   int32_t *__restrict__ rpos = s.r_pos + (int64_t)set * s.cap;
   for (int32_t e0 = 0; e0 < L; e0 += 16) {
     const int32_t e = e0 + gl;
-    const int32_t mine = (e < L) ? tmp[p0 + e] : 0x7FFFFFFF;
+    int32_t mine = 0x7FFFFFFF, rowrel = 0;
+    if (e < L) {
+      if (staged) { const int2 m2 = stg[p0 + e]; mine = m2.x; rowrel = m2.y; }
+      else mine = tmp[p0 + e];
+    }
     uint4 h = make_uint4(0, 0, 0, 0), d0 = h, d1 = h;
     if (e < L) {  // the record gather does not depend on the rank: issue it first
       const int32_t *f = feat + (int64_t)mine * 12;
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
     }
     int32_t rank = 0;
     for (int32_t j0 = 0; j0 < L; j0 += 16) {
-      const int32_t other = (j0 + gl < L) ? tmp[p0 + j0 + gl] : 0x7FFFFFFF;
+      const int32_t other = (j0 + gl < L) ? (staged ? stg[p0 + j0 + gl].x : tmp[p0 + j0 + gl]) : 0x7FFFFFFF;
       const int32_t m = min(16, L - j0);
       for (int32_t j = 0; j < m; j++) rank += (__shfl(other, j, 16) < mine) ? 1 : 0;
     }
@@ -207,12 +211,13 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
       suv[p] = (uint32_t)h.x | ((uint32_t)h.y << 16);
       sdesc[2 * (int64_t)p] = d0;
       sdesc[2 * (int64_t)p + 1] = d1;
-      // row order for the stereo search: only the bin position is scattered (4 B;
-      // scattering whole 40-byte records here cost 60 us per step), the search
-      // gathers the records from the bin-ordered arrays.  Order inside a row is
-      // irrelevant (the matcher minimises a (cost, bin position) key).
+      // row order for the stereo search: only the bin position is scattered (4 B), the search
+      // gathers the records from the bin-ordered arrays.  Order inside a row is irrelevant (the
+      // matcher minimises a (cost, bin position) key): detected features bring their rank in the
+      // row along (emit_features), caller-supplied ones take a ticket here.
       const int32_t row = (int32_t)h.w * s.H + (int32_t)h.y;
-      const int32_t rp = rs[row] + atomicAdd(&rcur[row], 1);
+      // (the rank is clamped into the row's range: a corrupt rank must show up as a wrong result, never as a stray write)
+      const int32_t rp = min(rs[row] + (staged ? rowrel : atomicAdd(&rcur[row], 1)), rs[row + 1] - 1);
       rpos[rp] = p;
     }
   }

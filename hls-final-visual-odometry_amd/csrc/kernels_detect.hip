@@ -502,15 +502,32 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   // the slots is undone by bin_sort.  The (class, v) row counts of the chunk --
   // its blocks span only a few pixel rows -- are first added up in LDS and flushed
   // with one global atomic per row that occurs (this phase is bound by the rate of
-  // L2 atomics: ~2 per feature before, ~1.15 now).
+  // L2 atomics: ~3 per feature in round 1 -- bin slot, row count, row cursor in bin_sort -- ~1.15 now).
   constexpr int ROWS_LDS = 64;
   __shared__ int32_t sRow[4 * ROWS_LDS];
+  __shared__ uint16_t sLoc[4 * VH_CHUNK];  // rank of each feature of the chunk among those of its (class, v) row
   const int32_t blk_first = chunk * VH_CHUNK, blk_last = min(blk_first + VH_CHUNK, g.nblocks) - 1;
   const int32_t v_first = ((blk_first / g.nbx) * n1 + g.n + VH_MARGIN) * g.scale;                      // smallest v a feature of this chunk can have
   const int32_t v_span = ((blk_last / g.nbx) * n1 + g.n + VH_MARGIN + g.n) * g.scale + g.scale - v_first;  // ... and one past the largest, relative
   const bool rows_in_lds = v_span <= ROWS_LDS;
+  int32_t *__restrict__ rowh = s.row_hist + (int64_t)set * 4 * s.H;
   if (rows_in_lds) {
+    // (a) count the chunk's features per row in LDS, remembering each one's rank in its row;
+    // (b) one returning global atomic per row that occurs reserves the chunk's range of the
+    //     row (row_hist ends up as the row's total, bin_scan turns it into row_start);
+    // (c) rank in row = reserved offset + rank in chunk: bin_sort needs no atomic for the row index
     for (int32_t k = tid; k < 4 * ROWS_LDS; k += 256) sRow[k] = 0;
+    __syncthreads();
+    for (int32_t f = tid; f < total && base + f < cap; f += 256) {  // (features beyond the capacity are dropped everywhere)
+      const uint32_t e = sList[f];
+      const int32_t vv = (int32_t)((e >> 14) & 0x3FFF) * g.scale, c = e >> 28;
+      sLoc[f] = (uint16_t)atomicAdd(&sRow[c * ROWS_LDS + (vv - v_first)], 1);
+    }
+    __syncthreads();
+    for (int32_t k = tid; k < 4 * ROWS_LDS; k += 256) {
+      const int32_t cnt = sRow[k], c = k / ROWS_LDS, vv = v_first + k % ROWS_LDS;
+      if (cnt) sRow[k] = atomicAdd(&rowh[c * s.H + vv], cnt);
+    }
     __syncthreads();
   }
   for (int32_t f = tid; f < total; f += 256) {
@@ -521,17 +538,9 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     const int32_t ubin = s.binsize == 1 ? uu : (int32_t)__umulhi((uint32_t)uu, s.inv_binsize);
     const int32_t vbin = s.binsize == 1 ? vv : (int32_t)__umulhi((uint32_t)vv, s.inv_binsize);
     const int32_t b = (c * s.ubn + min(ubin, s.ubn - 1)) * s.vbn + min(vbin, s.vbn - 1);
+    const int32_t rowrel = rows_in_lds ? sRow[c * ROWS_LDS + (vv - v_first)] + (int32_t)sLoc[f] : atomicAdd(&rowh[c * s.H + vv], 1);
     const int32_t slot = atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
-    if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = fi;
-    if (rows_in_lds) atomicAdd(&sRow[c * ROWS_LDS + (vv - v_first)], 1);
-    else atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], 1);
-  }
-  if (rows_in_lds) {
-    __syncthreads();
-    for (int32_t k = tid; k < 4 * ROWS_LDS; k += 256) {
-      const int32_t cnt = sRow[k], c = k / ROWS_LDS, vv = v_first + k % ROWS_LDS;
-      if (cnt) atomicAdd(&s.row_hist[(int64_t)set * 4 * s.H + c * s.H + vv], cnt);
-    }
+    if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = make_int2(fi, rowrel);
   }
 
   // phase B: 16 lanes per feature, lane k = sample point k; two features per lane

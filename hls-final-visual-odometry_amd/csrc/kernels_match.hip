@@ -527,7 +527,7 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   for (int32_t qi = 0; qi < Q; qi++) {
     const int32_t q = q0 + L * qi + l;
     valid[qi] = q < q1;
-    qp[qi] = qpos[valid[qi] ? q : q0];  // row order holds bin positions; the records are gathered from the bin-ordered arrays
+    qp[qi] = min(max(qpos[valid[qi] ? q : q0], 0), s.cap - 1);  // row order holds bin positions; the records are gathered from the bin-ordered arrays
     uv1[qi] = quv[qp[qi]];
     a0[qi] = qdesc[2 * (int64_t)qp[qi]]; a1[qi] = qdesc[2 * (int64_t)qp[qi] + 1];
     const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
@@ -543,7 +543,9 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   const int32_t r1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VHI + 1]);
   for (int32_t rc = r0; rc < r1; rc += 64) {
     const int32_t mcnt = min(64, r1 - rc);
-    const int32_t cp = cpos[min(rc + lane, r1 - 1)];  // slots past the end repeat the last candidate: same key, harmless
+    // slots past the end repeat the last candidate: same key, harmless.  The position is clamped into the class's
+    // range (a corrupt row index must show up as a wrong result, never as a stray access).
+    const int32_t cp = min(max(cpos[min(rc + lane, r1 - 1)], pbase), pbase + pcnt - 1);
     const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
     uint32_t gu = 0;
     if (!SPEC) gu = cuv[cp];
@@ -610,7 +612,7 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
       const int32_t x1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + min(v1 + a.disp_tol, s.H - 1) + 1]);
       uint64_t k = ~0ull;
       for (int32_t x = x0 + lane; x < x1; x += 64) {
-        const int32_t cp = cpos[x];
+        const int32_t cp = min(max(cpos[x], pbase), pbase + pcnt - 1);
         k = min(k, tested_key_uniform_query(qd, qlo2, span2, cuv[cp], cdesc[2 * (int64_t)cp], cdesc[2 * (int64_t)cp + 1], (uint32_t)(cp - pbase)));
       }
       k = wave_min_u64(k);

@@ -81,7 +81,7 @@ struct VhSets {
   int32_t *hist;
   int32_t *cursor;
   int32_t *tmp_idx;
-  int32_t *stage;      // [set][nbins][stage_cap] feature indices appended by emit_features (arbitrary order)
+  int2 *stage;         // [set][nbins][stage_cap] {feature index, rank in its (class, v) row} appended by emit_features (arbitrary order)
   int32_t *count;
   // row index (stereo search): the same records ordered by (class, v)
   int32_t *row_start;  // [set][4*H+1]
