@@ -236,6 +236,7 @@ def main():
     if use_dist:
         # RCCL only carries the barrier and the MAX-reduced timing: streams never exchange data
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")  # (only the single-process rehearsal lacks it; torch.distributed.run sets it)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = entry.load_package()

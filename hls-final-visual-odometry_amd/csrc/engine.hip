@@ -174,7 +174,7 @@ struct Group {
       // VH_POISON=1 (test aid): fill every buffer that is not zero-initialised with 0xA5, so that a
       // kernel consuming memory nobody wrote misbehaves the same way on every box
       static const bool poison = [] { const char *e = getenv("VH_POISON"); return e && e[0] == '1'; }();
-      if (poison) VH_HIP(hipMemsetAsync(q, 0xA5, bytes, stream));
+      if (poison) { VH_HIP(hipMemset(q, 0xA5, bytes)); VH_HIP(hipDeviceSynchronize()); }  // (blocking: the buffer's first user may be any stream)
     }
     *out = (T *)q;
     return VH_OK;
