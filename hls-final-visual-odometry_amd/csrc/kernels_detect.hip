@@ -205,13 +205,34 @@ template <int N> struct DetTile {
   static constexpr int N1 = N + 1, TBX = 32, TBY = 8;
   static constexpr int FW = TBX * N1 + 2 * N, FH = TBY * N1 + 2 * N;
   static constexpr int IW = FW + 4, IH = FH + 4;
-  static constexpr int DW = (IW + 3 + 3) / 4;  // dwords per staged row (room for the 0..3 byte alignment offset)
+  // Tile origins are 32*N1 columns apart, so response column 0 always sits at byte OFF of an aligned dword
+  static constexpr int OFF = (VH_MARGIN - 2) & 3;
+  static constexpr int DW = (IW + 3 + 3) / 4;  // dwords per staged row (room for the alignment offset)
   static constexpr int IP = DW * 4;
-  static constexpr int FP = FW + (FW & 1);     // response row pitch (i16), kept even
-  static constexpr int NSEG = (256 / FW) > 0 ? (256 / FW) : 1;
-  static constexpr int ROWS = (FH + NSEG - 1) / NSEG;
+  // The filter pass works on groups of 4 response columns that start at a staged dword: column cx is
+  // column OFF + cx of the staged row and of the response rows (pitch FP, int16).
+  static constexpr int G = (FW + OFF + 3) / 4;
+  static constexpr int FP = 4 * G;
+  // a lane filters one group over ROWS consecutive rows after 4 rows of run-in; SEG = number of row
+  // segments, picked for the fewest wave instructions (whole waves x rows passed)
+  static constexpr int seg_cost(int s) {
+    const int rows = (FH + s - 1) / s, waves = (G * s + 63) / 64;
+    return G * s > 256 ? (1 << 30) : waves * ((rows + 4) * 28 + rows * 26);
+  }
+  static constexpr int best_seg() {
+    int b = 1;
+    for (int s = 2; s <= 8; s++)
+      if (seg_cost(s) < seg_cost(b)) b = s;
+    return b;
+  }
+  static constexpr int SEG = best_seg();
+  static constexpr int ROWS = (FH + SEG - 1) / SEG;
+  static constexpr int BIAS = 8192;  // stored responses are f + BIAS (positive int16; the NMS only compares)
+  static_assert(G + 1 <= DW, "a group reads its own and the next staged dword");
+  static_assert(G * SEG <= 256, "one lane per (group, row segment)");
+  static constexpr int LAST = FH - (SEG - 1) * ROWS;  // rows of the last segment
+  static_assert(LAST >= 1, "every segment has rows");
 };
-
 
 template <int N>
 __global__ void __launch_bounds__(256)
@@ -230,7 +251,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   const int32_t bx0 = blockIdx.x * T::TBX, by0 = blockIdx.y * T::TBY;
   const int32_t fx0 = VH_MARGIN + bx0 * N1, fy0 = VH_MARGIN + by0 * N1;
   const int32_t ix0 = fx0 - 2, iy0 = fy0 - 2;
-  const int32_t ax0 = ix0 & ~3, off = ix0 & 3;
+  const int32_t ax0 = ix0 - T::OFF;  // a multiple of 4 (DetTile::OFF)
 
   // 1. stage the image tile with aligned dword loads (zero outside the image)
   for (int32_t k = tid; k < T::IH * T::DW; k += 256) {
@@ -242,30 +263,64 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   }
   __syncthreads();
 
-  // 2. blob / checkerboard responses: one column per lane, sliding 5-row window
-  for (int32_t task = tid; task < T::FW * T::NSEG; task += 256) {
-    const int32_t seg = task / T::FW, cx = task - seg * T::FW;
+  // 2. blob / checkerboard responses, four columns per lane and two columns per register: the row
+  //    sums live in the 16-bit halves of a dword and are added with plain 32-bit adds (full-rate
+  //    instructions; every field stays in [0, 65535] through every intermediate, so no carry or
+  //    borrow crosses the halves).  f2 = (1,1,0,-1,-1)^T (x) (1,1,0,-1,-1) (filter.cpp:339-347,
+  //    :365-367), f1 = -S5x5 + 2*S3x3 + 7*centre (filter.cpp:461-463); both are stored + BIAS.
+  //    Per row and lane: one 8-byte LDS read, 7 byte permutes (the pairs (b_k, b_k+1) of the 8
+  //    bytes) and 14 adds for the row sums of 4 columns, ~26 instructions for the column pass and
+  //    one 8-byte store per plane -- about a third of one-column-per-lane with byte loads.
+  if (tid < T::G * T::SEG) {
+    const int32_t seg = tid / T::G, gq = tid - seg * T::G;
     const int32_t r0 = seg * T::ROWS;
-    const uint8_t *p = sI + r0 * T::IP + off + cx;
-    int32_t h5[5], h3[5], hc[5], cc[5];
+    {
+      constexpr uint32_t HB = 512u * 0x00010001u, KB = (uint32_t)T::BIAS * 0x00010001u;
+      const uint32_t *p = (const uint32_t *)sI + r0 * T::DW + gq;
+      uint32_t *o1 = (uint32_t *)sF1 + (r0 * T::FP + 4 * gq) / 2, *o2 = (uint32_t *)sF2 + (r0 * T::FP + 4 * gq) / 2;
+      // rolling state per register (index 0: columns 0,1 of the group; 1: columns 2,3)
+      uint32_t h5[2][5], h3[2][5], pc[2][4], cc[2][5], hcp[2], S5[2] = {0u, 0u};
 #pragma unroll
-    for (int32_t k = 0; k < 4; k++) {
-      const int32_t a = p[k * T::IP + 0], b = p[k * T::IP + 1], c = p[k * T::IP + 2], d = p[k * T::IP + 3], e = p[k * T::IP + 4];
-      h5[k + 1] = a + b + c + d + e; h3[k + 1] = b + c + d; hc[k + 1] = a + b - d - e; cc[k + 1] = c;
-    }
+      for (int32_t t = 0; t < T::ROWS + 4; t++) {
+        if (t - 4 < T::LAST || r0 + t - 4 < T::FH) {  // only the last segment can be short
+          const uint32_t A = p[t * T::DW], B = p[t * T::DW + 1];
+          // pk = bytes (k, k+1) of the 8 staged bytes, zero-extended to the halves
+          const uint32_t p0 = __builtin_amdgcn_perm(B, A, 0x0c010c00u), p1 = __builtin_amdgcn_perm(B, A, 0x0c020c01u),
+                         p2 = __builtin_amdgcn_perm(B, A, 0x0c030c02u), p3 = __builtin_amdgcn_perm(B, A, 0x0c040c03u),
+                         p4 = __builtin_amdgcn_perm(B, A, 0x0c050c04u), p5 = __builtin_amdgcn_perm(B, A, 0x0c060c05u),
+                         p6 = __builtin_amdgcn_perm(B, A, 0x0c070c06u);
+          const uint32_t a01 = p0 + p1, a23 = p2 + p3, a34 = p3 + p4, a56 = p5 + p6;
+          uint32_t n5[2], n3[2], nc[2], nz[2];
+          n3[0] = a23 + p1;           n3[1] = a34 + p5;             // b+c+d
+          n5[0] = n3[0] + p0 + p4;    n5[1] = n3[1] + p2 + p6;      // a+b+c+d+e
+          nc[0] = (a01 + HB) - a34;   nc[1] = (a23 + HB) - a56;     // a+b-d-e + 512
+          nz[0] = p2;                 nz[1] = p4;                   // c
+          uint32_t f1[2], f2[2];
 #pragma unroll
-    for (int32_t i = 0; i < T::ROWS; i++) {
-      const int32_t fr = r0 + i;
-      if (fr < T::FH) {
+          for (int32_t h = 0; h < 2; h++) {
+            // slots 0..4 = staged rows t-4..t, the 5-row window of response row t-4
+            const uint32_t old5 = h5[h][0];  // row t-5
 #pragma unroll
-        for (int32_t k = 0; k < 4; k++) { h5[k] = h5[k + 1]; h3[k] = h3[k + 1]; hc[k] = hc[k + 1]; cc[k] = cc[k + 1]; }
-        const uint8_t *q = p + (i + 4) * T::IP;
-        const int32_t a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
-        h5[4] = a + b + c + d + e; h3[4] = b + c + d; hc[4] = a + b - d - e; cc[4] = c;
-        // f2 = (1,1,0,-1,-1)^T (x) (1,1,0,-1,-1)   (filter.cpp:339-347,:365-367)
-        // f1 = -S5x5 + 2*S3x3 + 7*centre            (filter.cpp:461-463)
-        sF2[fr * T::FP + cx] = (int16_t)(hc[0] + hc[1] - hc[3] - hc[4]);
-        sF1[fr * T::FP + cx] = (int16_t)(-(h5[0] + h5[1] + h5[2] + h5[3] + h5[4]) + 2 * (h3[1] + h3[2] + h3[3]) + 7 * cc[2]);
+            for (int32_t k = 0; k < 4; k++) { h5[h][k] = h5[h][k + 1]; h3[h][k] = h3[h][k + 1]; cc[h][k] = cc[h][k + 1]; }
+            h5[h][4] = n5[h]; h3[h][4] = n3[h]; cc[h][4] = nz[h];
+            S5[h] += n5[h];
+            if (t >= 5) S5[h] -= old5;
+            // pc slots 0..3 = hc(r) + hc(r+1) (+1024) for r = t-4..t-1
+#pragma unroll
+            for (int32_t k = 0; k < 3; k++) pc[h][k] = pc[h][k + 1];
+            if (t > 0) pc[h][3] = hcp[h] + nc[h];
+            hcp[h] = nc[h];
+            if (t >= 4) {
+              const uint32_t S3 = h3[h][1] + h3[h][2] + h3[h][3];
+              f2[h] = (pc[h][0] + KB) - pc[h][3];
+              f1[h] = ((S3 + S3) + (__umul24(cc[h][2], 7u) + KB)) - S5[h];
+            }
+          }
+          if (t >= 4) {
+            *(uint2 *)(o1 + (t - 4) * (T::FP / 2)) = make_uint2(f1[0], f1[1]);
+            *(uint2 *)(o2 + (t - 4) * (T::FP / 2)) = make_uint2(f2[0], f2[1]);
+          }
+        }
       }
     }
   }
@@ -301,7 +356,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
     const int32_t lane = tid & 63;
 #pragma unroll
     for (int32_t plane = 0; plane < 2; plane++) {
-      const int16_t *b = (plane ? sF2 : sF1) + fy * T::FP + fx;
+      const int16_t *b = (plane ? sF2 : sF1) + fy * T::FP + fx + T::OFF;
       int32_t vn = b[0], vx = vn, pn = 0, px = 0;
 #pragma unroll
       for (int32_t j = 0; j < N1; j++) {
@@ -318,7 +373,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
       pos[2 * plane + 1] = (uint32_t)px;
 #pragma unroll
       for (int32_t mm = 0; mm < 2; mm++) {  // 0: the block minimum, 1: the block maximum
-        const bool cand = have_block && (mm ? vx >= g.tau : vn <= -g.tau);
+        const bool cand = have_block && (mm ? vx >= T::BIAS + g.tau : vn <= T::BIAS - g.tau);
         const uint32_t pc = mm ? (uint32_t)px : (uint32_t)pn;
         const uint64_t bal = __ballot(cand);
         if (bal) {  // wave-uniform
@@ -345,7 +400,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
       for (int32_t e = tid & 127; e < nq; e += 128) {
         const uint32_t q = sQueue[mm * 512 + e];
         const int32_t owner = q & 255, type = (q >> 8) & 3, cy = (q >> 10) & 63, cx = q >> 16;
-        const int16_t *F = (type & 2) ? sF2 : sF1;
+        const int16_t *F = ((type & 2) ? sF2 : sF1) + T::OFF;
         int32_t v[WN * WN];
         if (decltype(no_clip)::value) {
           const int16_t *w = F + (cy - N) * T::FP + (cx - N);
