@@ -475,6 +475,26 @@ __device__ __forceinline__ int32_t wave_incl_scan(int32_t v) {
 __constant__ int8_t c_desc_dx[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
 __constant__ int8_t c_desc_dy[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
 
+#ifdef VH_EMIT_TIMING
+// debug build only (EXTRA=-DVH_EMIT_TIMING): s_memtime ticks workgroups of emit_features spent per phase,
+// summed over workgroups: [0] prefix [1] phase A [2] A2 row ranks [3] bin slots + staging [4] phase B [5] workgroups;
+// [6] earliest start, [7] latest end (one launch between two resets)
+__device__ unsigned long long g_emit_t[8];
+extern "C" int32_t vh_debug_emit_timing(unsigned long long *out, int32_t reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_emit_t), sizeof(g_emit_t)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[8] = {0}; z[6] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_emit_t), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+#define VH_ETICK(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_emit_t[k], now_ - t_prev_); t_prev_ = now_; if ((k) == 4) atomicMax(&g_emit_t[7], now_); } } while (0)
+#define VH_ETICK_INIT unsigned long long t_prev_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) { atomicAdd(&g_emit_t[5], 1ull); atomicMin(&g_emit_t[6], t_prev_); }
+#else
+#define VH_ETICK(k) do { } while (0)
+#define VH_ETICK_INIT do { } while (0)
+#endif
+
+#ifndef VH_EMIT_NF
+#define VH_EMIT_NF 2
+#endif
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256)
 emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
@@ -490,6 +510,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const uint8_t *__restrict__ I = vh_image_ptr(im, id);
   const int32_t set = vh_image_set(im, id);
   const int32_t n1 = g.n + 1;
+  VH_ETICK_INIT;
 
   // features emitted by earlier chunks of this image
   int32_t part = 0;
@@ -502,6 +523,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   __syncthreads();
   const int32_t base = sBase;
   __syncthreads();
+  VH_ETICK(0);
 
   // phase A: each lane owns VH_CHUNK/256 consecutive blocks; the four 16-bit codes of a
   // block are handled as two dwords so every extract is one 32-bit op
@@ -549,6 +571,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   }
   __syncthreads();
   if (chunk == g.nchunks - 1 && tid == 0) count[set] = base + total;
+  VH_ETICK(1);
 
   // phase A2: bin histogram + per-bin staging + row histogram, one lane per
   // feature.  Kept out of the descriptor loop below: a returning atomic inside
@@ -560,7 +583,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   // L2 atomics: ~3 per feature in round 1 -- bin slot, row count, row cursor in bin_sort -- ~1.15 now).
   constexpr int ROWS_LDS = 64;
   __shared__ int32_t sRow[4 * ROWS_LDS];
-  __shared__ uint16_t sLoc[4 * VH_CHUNK];  // rank of each feature of the chunk among those of its (class, v) row
+  __shared__ __attribute__((aligned(16))) uint16_t sLoc[4 * VH_CHUNK];  // rank of each feature of the chunk among those of its (class, v) row
   const int32_t blk_first = chunk * VH_CHUNK, blk_last = min(blk_first + VH_CHUNK, g.nblocks) - 1;
   const int32_t v_first = ((blk_first / g.nbx) * n1 + g.n + VH_MARGIN) * g.scale;                      // smallest v a feature of this chunk can have
   const int32_t v_span = ((blk_last / g.nbx) * n1 + g.n + VH_MARGIN + g.n) * g.scale + g.scale - v_first;  // ... and one past the largest, relative
@@ -585,6 +608,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     }
     __syncthreads();
   }
+  VH_ETICK(2);
   for (int32_t f = tid; f < total; f += 256) {
     const int32_t fi = base + f;
     if (fi >= cap) break;
@@ -598,59 +622,93 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = make_int2(fi, rowrel);
   }
 
-  // phase B: 16 lanes per feature, lane k = sample point k; two features per lane
-  // and loop trip so that both features' row loads are in flight together (the
-  // loop is bound by the load round trip, not by arithmetic)
+  VH_ETICK(3);
+  // phase B: 16 lanes per feature, lane k = sample point k; NF features per lane and loop trip.
+  // The 16 windows of a feature (5x5 bytes each) all lie in the 15x15 patch around it.  Fetched
+  // window by window (5 loads per lane) a wave-wide load touches ~8 cache lines per feature, 40
+  // per feature in all, and the kernel is bound by exactly that: the rate at which the vector
+  // memory pipe walks the distinct lines of a load, whatever their bytes.  So the patch is
+  // fetched ONCE, row k by lane k as one 16-byte load at the (unaligned) byte u-7 -- 15 lines per
+  // feature, plus the rows that straddle a line -- and handed round through LDS, from where every
+  // lane takes its five row segments at offsets that depend on the lane alone.  A lane group
+  // lives inside one wave and a wave's LDS instructions execute in order: no barrier is needed.
   const int32_t grp = tid >> 4, k = tid & 15;
   const int32_t dx = c_desc_dx[k], dy = c_desc_dy[k];
+  const int32_t sh = g.scale - 1;  // scale is 1 or 2
   int32_t *__restrict__ out = feat + (int64_t)set * cap * 12;
-  for (int32_t f0 = 0; f0 < total; f0 += 32) {
-    int32_t fs[2], us[2], vs[2], cs[2];
-    bool lives[2];
-    uint32_t lo[2][5], hi[2][5];
-    int32_t o8s[2];
+  uint32_t *__restrict__ fuv = s.f_uv + (int64_t)set * cap;
+  // lane L<4 writes the header word, lane 4+j the descriptor dword j = pair[2j] | pair[2j+1]<<16
+  const int32_t gbase = (tid & 63) & ~15, j = (k >= 4) ? (k - 4) : 0;
+  // (branch-free word select: the lane's role is loop-invariant; word 2, val, is zeroed on packing, matcher.cpp:667)
+  const uint32_t m_u = k == 0 ? ~0u : 0u, m_v = k == 1 ? ~0u : 0u, m_c = k == 3 ? ~0u : 0u, m_d = k >= 4 ? ~0u : 0u;
+  constexpr int NF = VH_EMIT_NF;  // features per lane group and trip
+  static_assert(16 * NF * 16 * 16 <= (int)sizeof(sLoc), "the patches reuse sLoc");
+  __syncthreads();  // sLoc is dead from here on
+  uint32_t *sPatch = (uint32_t *)sLoc + grp * (NF * 64);  // [feature of the trip][16 rows: 15 + lane 15's spare][4 dwords] of this lane group
+  const int32_t prk = min(k, 14) - 7;                    // patch row this lane fetches (lane 15: row 14 again, no branch)
+  const int32_t rd0 = (dy + 5) * 4 + ((dx + 5) >> 2);         // first dword of the lane's window in a patch
+  const uint32_t psel = 0x03020100u + (uint32_t)((dx + 5) & 3) * 0x01010101u;  // v_perm selector of its first four bytes there
+  for (int32_t f0 = 0; f0 < total; f0 += 16 * NF) {
+    int32_t fs[NF], us[NF], vs[NF], cs[NF];
+    bool lives[NF];
+    uint32_t lo[NF][5], hi[NF][5];
+    uint32_t sel[NF];
+    typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+    u32x4a1 prow[NF];
 #pragma unroll
-    for (int32_t h = 0; h < 2; h++) {
+    for (int32_t h = 0; h < NF; h++) {
       fs[h] = f0 + 16 * h + grp;
       lives[h] = fs[h] < total;
       const uint32_t e = sList[lives[h] ? fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
       us[h] = e & 0x3FFF; vs[h] = (e >> 14) & 0x3FFF; cs[h] = e >> 28;
+      sel[h] = psel;
       if (ALIGNED) {
-        // each 5-byte row segment comes from two aligned dwords; 32-bit byte offsets
-        // from the (wave-uniform) image base: images are < 2^28 bytes
-        const int32_t x0 = us[h] + dx - 2;
-        o8s[h] = (x0 & 3) * 8;
-        const uint32_t off0 = (uint32_t)((vs[h] + dy - 2) * g.bplm + (x0 & ~3));
-#pragma unroll
-        for (int32_t r = 0; r < 5; r++) {
-          // one 8-byte load per row segment (4-byte aligned: global memory takes it), not two dword loads:
-          // the kernel is bound by the number of scattered load instructions, not by their bytes
-          typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
-          const u32x2a4 w2 = *(const u32x2a4 *)(I + (off0 + (uint32_t)(r * g.bplm)));
-          lo[h][r] = w2.x; hi[h][r] = w2.y;
-        }
+        // 32-bit byte offsets from the (wave-uniform) image base: images are < 2^28 bytes, rows < 2^14
+        prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(us[h] - 7)));
       }
     }
+    if (ALIGNED) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int32_t h = 0; h < 2; h++) {
+      for (int32_t h = 0; h < NF; h++)
+        *(uint4 *)(sPatch + (h * 16 + k) * 4) = make_uint4(prow[h].x, prow[h].y, prow[h].z, prow[h].w);
+#pragma unroll
+      for (int32_t h = 0; h < NF; h++)
+#pragma unroll
+        for (int32_t r = 0; r < 5; r++) {
+          lo[h][r] = sPatch[h * 64 + rd0 + 4 * r];
+          hi[h][r] = sPatch[h * 64 + rd0 + 4 * r + 1];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int32_t h = 0; h < NF; h++) {
       const int32_t u = us[h], v = vs[h];
       // 5x5 Sobel pair at (u+dx, v+dy): du = smooth_y (x) deriv_x, dv = deriv_y (x) smooth_x
       // (filter.cpp:288-318 column pass, :132-171 / :79-127 row passes)
       int32_t a_du = 0, a_dv = 0;
       if (ALIGNED) {
+        // With w = bytes x0..x0+3 and w' = bytes x0+1..x0+4 of a row, its sums are byte dot products
+        // (v_dot4_u32_u8, accumulating): a+2b-2d-e = w.(1,2,0,0) - w'.(0,0,2,1) and
+        // a+4b+6c+4d+e = w.(1,4,6,0) + w'.(0,0,4,1); the column weights (1,4,6,4,1) resp.
+        // (1,2,0,-2,-1) are folded into the byte weights, positive and negative parts apart.
+        uint32_t du_p = 0, du_n = 0, dv_p = 0, dv_n = 0;
 #pragma unroll
         for (int32_t r = 0; r < 5; r++) {
-          const uint32_t w = (uint32_t)(((uint64_t)hi[h][r] << 32 | lo[h][r]) >> o8s[h]);  // bytes x0..x0+3
-          const int32_t ee = (hi[h][r] >> o8s[h]) & 0xFF;                                   // byte x0+4
-          // row sums as byte dot products (v_dot4_u32_u8)
-          const int32_t rowS = (int32_t)__builtin_amdgcn_udot4(w, 0x04060401u, (uint32_t)ee, false);
-          const int32_t rowD = (int32_t)__builtin_amdgcn_udot4(w, 0x00000201u, 0u, false) -
-                               (int32_t)__builtin_amdgcn_udot4(w, 0x02000000u, (uint32_t)ee, false);
-          const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
-          const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
-          a_du += sw * rowD;
-          a_dv += dw * rowS;
+          const uint32_t w = __builtin_amdgcn_perm(hi[h][r], lo[h][r], sel[h]);
+          const uint32_t w1 = __builtin_amdgcn_perm(hi[h][r], lo[h][r], sel[h] + 0x01010101u);
+          const uint32_t sw = (r == 0 || r == 4) ? 1u : (r == 2 ? 6u : 4u);
+          du_p = __builtin_amdgcn_udot4(w, sw * 0x00000201u, du_p, false);
+          du_n = __builtin_amdgcn_udot4(w1, sw * 0x01020000u, du_n, false);
+          if (r != 2) {
+            const uint32_t dw = (r == 0 || r == 4) ? 1u : 2u;
+            uint32_t &acc = r < 2 ? dv_p : dv_n;
+            acc = __builtin_amdgcn_udot4(w, dw * 0x00060401u, acc, false);
+            acc = __builtin_amdgcn_udot4(w1, dw * 0x01040000u, acc, false);
+          }
         }
+        a_du = (int32_t)(du_p - du_n);
+        a_dv = (int32_t)(dv_p - dv_n);
       } else {
         const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (u + dx - 2);
 #pragma unroll
@@ -669,21 +727,15 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
       const uint32_t du = (uint32_t)min(255, max(0, (a_du >> 7) + 128));
       const uint32_t dv = (uint32_t)min(255, max(0, (a_dv >> 7) + 128));
       const uint32_t pair = du | (dv << 8);
-      // lane L<4 writes the header word, lane 4+j the descriptor dword j = pair[2j] | pair[2j+1]<<16
-      const int32_t lane = tid & 63, gbase = lane & ~15;
-      const int32_t j = (k >= 4) ? (k - 4) : 0;
       const uint32_t plo = __shfl(pair, gbase + 2 * j), phi = __shfl(pair, gbase + 2 * j + 1);
-      uint32_t word;
-      if (k == 0) word = (uint32_t)(u * g.scale);
-      else if (k == 1) word = (uint32_t)(v * g.scale);
-      else if (k == 2) word = 0;  // val is zeroed on packing (matcher.cpp:667)
-      else if (k == 3) word = (uint32_t)cs[h];
-      else word = plo | (phi << 16);
+      const uint32_t word = (((uint32_t)u << sh) & m_u) | (((uint32_t)v << sh) & m_v) | ((uint32_t)cs[h] & m_c) | ((plo | (phi << 16)) & m_d);
       const int32_t fi = base + fs[h];
-      if (lives[h] && k < 12 && fi < cap) out[(int64_t)fi * 12 + k] = (int32_t)word;
-      if (lives[h] && k == 12 && fi < cap) s.f_uv[(int64_t)set * cap + fi] = (uint32_t)(u * g.scale) | ((uint32_t)(v * g.scale) << 16);
+      const bool okf = lives[h] && fi < cap;
+      if (okf && k < 12) out[(int64_t)fi * 12 + k] = (int32_t)word;
+      if (okf && k == 12) fuv[fi] = (uint32_t)(u << sh) | ((uint32_t)(v << sh) << 16);
     }
   }
+  VH_ETICK(4);
 }
 
 // --------------------------------------------------------------------- planes
