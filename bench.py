@@ -389,6 +389,8 @@ def main():
                             "note": "chosen per launch from the share of queries whose best candidate over the walked region "
                                     "lies outside their own window (DESIGN.md 4.1); results are identical either way"},
             "kernels_us_per_launch": {n_: round(v["us_per_launch"], 2) for n_, v in prof.items()},
+            # detection runs in sub-batches of streams (engine.hip): several launches per step
+            "kernels_launches_per_step": {n_: round(v["launches"] / args.steps, 2) for n_, v in prof.items()},
             "kernels_us_per_launch_exclusive": {n_: round(v["us_per_launch"], 2) for n_, v in prof_excl.items()},
             "parity_scope": "primitives (computeFeatures, createIndexVector, findMatch, flow matching) pinned to the reference; "
                             "stereo/quad composition per SURVEY A.7 (absent from the reference: unpinned)",

@@ -363,12 +363,18 @@ struct Group {
     }
     if (ev_read_valid[pair_cur]) VH_HIP(hipStreamWaitEvent(stream, ev_read[pair_cur], 0));
     if ((rc = zero_bin_counters(set0, nsets, d_chunk_count, 2 * (int64_t)S * g.nchunks))) return rc;
-    // All streams in one launch per kernel.  Splitting the group into sub-batches
-    // (VH_SUBBATCH=n), hoping that each sub-batch's latency-bound tail would hide
-    // beside the previous frame's flow search, was measured on MI355X and loses
-    // 9 % (n=2) to 34 % (n=8): fewer, larger launches win.
+    // The group is detected in up to four sub-batches of streams, one after the other on this
+    // stream: the latency-bound kernels of a sub-batch (emit_features, bin_scan, bin_sort: < 45 %
+    // of the VALU issue slots) then run beside the issue-bound ones of its neighbours and of the
+    // previous frame's search instead of all at once.  Measured on MI355X, KITTI, S = 256 (with
+    // the post stream): 1 / 2 / 4 / 8 / 16 sub-batches = 94.9 / 95.9 / 97.1 / 92.1 / 82.0 k pairs/s
+    // -- below ~12 k detection workgroups per launch the launches themselves cost more.  (Round 1
+    // measured the opposite, -9 % at n = 2: its kernels were not yet issue-bound.)  Sub-batches on
+    // two alternating streams lose 8 %.  VH_SUBBATCH=n overrides.
     const int32_t ncam = dI2 ? 2 : 1;
-    static const int subbatch = [] { const char *ev = getenv("VH_SUBBATCH"); return ev ? atoi(ev) : 1; }();
+    static const int subbatch_env = [] { const char *ev = getenv("VH_SUBBATCH"); return ev ? atoi(ev) : 0; }();
+    const int64_t det_wgs = (int64_t)S * ncam * ((g.nblocks + 255) / 256);
+    const int32_t subbatch = subbatch_env > 0 ? subbatch_env : (serial ? 1 : (int32_t)std::min<int64_t>(4, det_wgs / 12000));
     const int32_t nsub = std::max(1, std::min(subbatch, S));
     const int32_t ssub = (S + nsub - 1) / nsub;
     for (int32_t s0 = 0; s0 < S; s0 += ssub) {
@@ -801,11 +807,12 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
   if (serial && serial[0] == '1') gq->match_stream = gq->post_stream = gq->own_stream, gq->serial = true;
   else {
     ok = hipStreamCreateWithPriority(&gq->match_stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
-    // The chain/emission step can run on a stream of its own (VH_POST_STREAM=1) so
-    // that consecutive flow searches run back to back; measured on MI355X this
-    // LOSES ~17 %: the short kernels starve beside the saturating flow search
-    // and delay the detection that waits for them.  Default: same stream.
-    if (ok && getenv("VH_POST_STREAM")) ok = hipStreamCreateWithPriority(&gq->post_stream, hipStreamNonBlocking, prio_lo) == hipSuccess, gq->own_post = true;
+    // The chain/emission step runs on a stream of its own so that consecutive searches run back
+    // to back and the two short, latency-bound kernels hide beside the next search: +2.8 % on
+    // MI355X (KITTI, S = 256).  (Round 1 measured -17 % for the same switch, when the searches
+    // did not yet fill the chip's issue slots.)  VH_POST_STREAM=0: same stream as the search.
+    const char *pse = getenv("VH_POST_STREAM");
+    if (ok && !(pse && pse[0] == '0')) ok = hipStreamCreateWithPriority(&gq->post_stream, hipStreamNonBlocking, prio_lo) == hipSuccess, gq->own_post = true;
     else gq->post_stream = gq->match_stream;
   }
   for (int k = 0; k < 2 && ok; k++)
