@@ -214,14 +214,17 @@ template <int N> struct DetTile {
   static constexpr int G = (FW + OFF + 3) / 4;
   static constexpr int FP = 4 * G;
   // a lane filters one group over ROWS consecutive rows after 4 rows of run-in; SEG = number of row
-  // segments, picked for the fewest wave instructions (whole waves x rows passed)
+  // segments, picked for the shortest pass PER WAVE (then the fewest waves): a workgroup's four
+  // waves sit on the four SIMDs of its CU, and a pass that keeps only two of them busy loads two
+  // SIMDs with everybody's filter pass -- the fewest wave instructions in total (3 segments, 2
+  // waves) measured 410 us per S = 256 launch, the balanced choice (7 segments, 4 waves) 387 us.
   static constexpr int seg_cost(int s) {
     const int rows = (FH + s - 1) / s, waves = (G * s + 63) / 64;
-    return G * s > 256 ? (1 << 30) : waves * ((rows + 4) * 28 + rows * 26);
+    return G * s > 256 ? (1 << 30) : 1000 * ((rows + 4) * 28 + rows * 26) + waves;
   }
   static constexpr int best_seg() {
     int b = 1;
-    for (int s = 2; s <= 8; s++)
+    for (int s = 2; s <= 16; s++)
       if (seg_cost(s) < seg_cost(b)) b = s;
     return b;
   }
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(256)
 detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__restrict__ chunk_count) {
   using T = DetTile<N>;
   constexpr int N1 = T::N1, WN = 2 * N + 1;
-  constexpr int X_BYTES = (T::IH * T::IP > 5120) ? T::IH * T::IP : 5120;
+  constexpr int X_BYTES = (T::IH * T::IP > 6144) ? T::IH * T::IP : 6144;  // image tile, later queues (4 KB) + codes (2 KB)
   __shared__ __attribute__((aligned(16))) int16_t sF1[T::FH * T::FP];
   __shared__ __attribute__((aligned(16))) int16_t sF2[T::FH * T::FP];
   // scratch: first the staged image tile, later the NMS candidate queues and pass flags
@@ -344,46 +347,64 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   const int32_t bx = bx0 + lbx, by = by0 + lby;
   const bool have_block = bx < g.nbx && by < g.nby;
   const int32_t fx = N + lbx * N1, fy = N + lby * N1;
-  // queues: [0] minima, [1] maxima; entry = owner | type << 8 | row << 10 | column << 16
+  // queues: [0] minima, [1] maxima; entry = owner | type << 8 | (PACKED ? extremum : row << 3 | column of it in the block) << 16
+  // With odd N a block row is N1/2 aligned dwords of the response rows, so (a) takes the block
+  // extrema with packed 16-bit min/max over whole dwords -- the VALUE only; where in the block it
+  // first occurs is looked up in (b), for the ~13 % that are candidates at all.
+  constexpr bool PACKED = (N & 1) != 0;
   uint32_t *sQueue = (uint32_t *)sX;             // [2][512]
-  uint32_t *sPass = sQueue + 1024;               // [256]: one byte per (block, type)
+  uint16_t *sCode = (uint16_t *)(sQueue + 1024); // [256][4]: position code of each (block, type) that survives
   __shared__ int32_t sQueueN[2];
   if (tid < 2) sQueueN[tid] = 0;
-  sPass[tid] = 0;
+  ((uint2 *)sCode)[tid] = make_uint2(VH_NO_CODE * 0x00010001u, VH_NO_CODE * 0x00010001u);
   __syncthreads();
-  uint32_t pos[4];
   {
+    typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
     const int32_t lane = tid & 63;
 #pragma unroll
     for (int32_t plane = 0; plane < 2; plane++) {
       const int16_t *b = (plane ? sF2 : sF1) + fy * T::FP + fx + T::OFF;
-      int32_t vn = b[0], vx = vn, pn = 0, px = 0;
+      int32_t vn, vx, pn = 0, px = 0;
+      if (PACKED) {
+        const i16x2 *bw = (const i16x2 *)b;  // fx + OFF and FP are even
+        i16x2 mn = bw[0], mx = mn;
 #pragma unroll
-      for (int32_t j = 0; j < N1; j++) {
+        for (int32_t j = 0; j < N1; j++) {
 #pragma unroll
-        for (int32_t i = 0; i < N1; i++) {
-          if (i == 0 && j == 0) continue;
-          const int32_t cur = b[j * T::FP + i], kk = (j << 6) | i;
-          const bool lt = cur < vn, gt = !lt && cur > vx;  // `else if`: first extremum wins (matcher.cpp:397-405)
-          vn = lt ? cur : vn; pn = lt ? kk : pn;
-          vx = gt ? cur : vx; px = gt ? kk : px;
+          for (int32_t d = 0; d < N1 / 2; d++) {
+            if (d == 0 && j == 0) continue;
+            const i16x2 w = bw[j * (T::FP / 2) + d];
+            mn = __builtin_elementwise_min(mn, w);
+            mx = __builtin_elementwise_max(mx, w);
+          }
+        }
+        vn = min((int32_t)mn.x, (int32_t)mn.y);
+        vx = max((int32_t)mx.x, (int32_t)mx.y);
+      } else {
+        vn = b[0]; vx = vn;
+#pragma unroll
+        for (int32_t j = 0; j < N1; j++) {
+#pragma unroll
+          for (int32_t i = 0; i < N1; i++) {
+            if (i == 0 && j == 0) continue;
+            const int32_t cur = b[j * T::FP + i], kk = (j << 3) | i;
+            const bool lt = cur < vn, gt = !lt && cur > vx;  // `else if`: first extremum wins (matcher.cpp:397-405)
+            vn = lt ? cur : vn; pn = lt ? kk : pn;
+            vx = gt ? cur : vx; px = gt ? kk : px;
+          }
         }
       }
-      pos[2 * plane] = (uint32_t)pn;
-      pos[2 * plane + 1] = (uint32_t)px;
 #pragma unroll
       for (int32_t mm = 0; mm < 2; mm++) {  // 0: the block minimum, 1: the block maximum
         const bool cand = have_block && (mm ? vx >= T::BIAS + g.tau : vn <= T::BIAS - g.tau);
-        const uint32_t pc = mm ? (uint32_t)px : (uint32_t)pn;
+        const uint32_t payload = PACKED ? (uint32_t)(mm ? vx : vn) : (uint32_t)(mm ? px : pn);
         const uint64_t bal = __ballot(cand);
         if (bal) {  // wave-uniform
           int32_t base = 0;
           if (lane == 0) base = atomicAdd(&sQueueN[mm], (int32_t)__popcll(bal));
           base = __builtin_amdgcn_readfirstlane(base);
           const int32_t rank = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          if (cand)
-            sQueue[mm * 512 + base + rank] =
-                (uint32_t)tid | ((uint32_t)(2 * plane + mm) << 8) | ((uint32_t)(fy + (pc >> 6)) << 10) | ((uint32_t)(fx + (pc & 63)) << 16);
+          if (cand) sQueue[mm * 512 + base + rank] = (uint32_t)tid | ((uint32_t)(2 * plane + mm) << 8) | (payload << 16);
         }
       }
     }
@@ -399,8 +420,23 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
     auto check = [&](auto is_max, auto no_clip) {
       for (int32_t e = tid & 127; e < nq; e += 128) {
         const uint32_t q = sQueue[mm * 512 + e];
-        const int32_t owner = q & 255, type = (q >> 8) & 3, cy = (q >> 10) & 63, cx = q >> 16;
+        const int32_t owner = q & 255, type = (q >> 8) & 3;
+        const int32_t ofy = N + (owner / T::TBX) * N1, ofx = N + (owner % T::TBX) * N1;  // the owner's block
         const int16_t *F = ((type & 2) ? sF2 : sF1) + T::OFF;
+        int32_t bj = 0, bi = 0;  // the extremum's row and column in the block
+        if (PACKED) {
+          // first occurrence of the extremum in scan order (matcher.cpp:393-417: strict comparisons, the first one stays)
+          const int32_t val = (int32_t)(q >> 16);
+          const int16_t *bb = F + ofy * T::FP + ofx;
+#pragma unroll
+          for (int32_t idx = N1 * N1 - 1; idx >= 0; idx--) {
+            const bool eq = bb[(idx / N1) * T::FP + idx % N1] == val;
+            bj = eq ? idx / N1 : bj; bi = eq ? idx % N1 : bi;
+          }
+        } else {
+          bj = (q >> 19) & 7; bi = (q >> 16) & 7;
+        }
+        const int32_t cy = ofy + bj, cx = ofx + bi;
         int32_t v[WN * WN];
         if (decltype(no_clip)::value) {
           const int16_t *w = F + (cy - N) * T::FP + (cx - N);
@@ -423,7 +459,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
         int32_t ext = centre;
 #pragma unroll
         for (int32_t k = 0; k < WN * WN; k++) ext = decltype(is_max)::value ? max(ext, v[k]) : min(ext, v[k]);
-        if (ext == centre) ((uint8_t *)sPass)[owner * 4 + type] = 1;
+        if (ext == centre) sCode[owner * 4 + type] = (uint16_t)((bj << 6) | bi);
       }
     };
     if (mm) { if (unclipped) check(std::true_type{}, std::true_type{}); else check(std::true_type{}, std::false_type{}); }
@@ -432,9 +468,8 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   __syncthreads();
   uint32_t codes[4];
   {
-    const uint32_t ok = sPass[tid];
-#pragma unroll
-    for (int32_t c = 0; c < 4; c++) codes[c] = ((ok >> (8 * c)) & 1) ? pos[c] : VH_NO_CODE;
+    const uint2 cw = ((const uint2 *)sCode)[tid];
+    codes[0] = cw.x & 0xFFFFu; codes[1] = cw.x >> 16; codes[2] = cw.y & 0xFFFFu; codes[3] = cw.y >> 16;
   }
 
   // 4. 8 bytes per block + the per-chunk survivor counts.  The counts are first
