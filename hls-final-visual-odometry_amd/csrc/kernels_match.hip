@@ -920,14 +920,22 @@ void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32
   VhMatchArgs m = a;
   static const int wide = [] { const char *e = getenv("VH_FLOW_WIDE_KEYS"); return e ? atoi(e) : 0; }();
   m.wide_keys = wide;
-  // One workgroup per 4 tiles of the capacity-sized tile list (the kernel loops, so
-  // any grid is correct; at typical densities most of these workgroups find no tile
-  // and exit at once).  VH_FLOW_WGS overrides (experiments).
+  // One workgroup per 4 tiles of the capacity-sized tile list (the kernel loops, so any grid is
+  // correct; at typical densities 4 of 5 of these workgroups find no tile and exit at once).  The
+  // width is made odd: workgroups go to the 8 XCDs round-robin by linear id, tile k of every
+  // (pass, stream) row costs about the same, and a width that is a multiple of 8 pins tile k of
+  // all rows to one XCD (measured at KITTI size, S = 256, k pairs/s: 128 -> 85.2, 129 -> 95.6,
+  // 520 -> 91.5, 523 -> 93.5).  Tight grids make the search itself ~5 % faster (57: 1628 us vs
+  // 1700 us alone) but the STEP slower (93.1 vs 98.8): the empty workgroups dilute the search's
+  // hold on the CUs and the latency-bound kernels of the other streams run beside it; 197..263 is
+  // a plateau (99.0 / 98.8).  An LDS pad as occupancy cap instead (VH_FLOW_LDS_PAD) loses with
+  // either grid.  VH_FLOW_WGS overrides (experiments).
   static const int wgs = [] { const char *e = getenv("VH_FLOW_WGS"); return e ? atoi(e) : 0; }();
-  const int32_t gx = wgs > 0 ? wgs : (s.max_tiles + 3) / 4;
+  const int32_t gx = wgs > 0 ? wgs : (((s.max_tiles + 3) / 4) | 1);
   dim3 grid(gx, m.npass, a.S);
-  if (speculative) hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), 0, st, s, m, best, redo);
-  else hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), 0, st, s, m, best, redo);
+  static const int pad = [] { const char *e = getenv("VH_FLOW_LDS_PAD"); return e ? atoi(e) : 0; }();
+  if (speculative) hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), pad, st, s, m, best, redo);
+  else hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), pad, st, s, m, best, redo);
 }
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st) {
