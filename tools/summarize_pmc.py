@@ -7,7 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "pmc_" + tag)
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "p*", "*", "*counter_collection.csv")):
+for d in sorted(glob.glob(os.path.join(src, "p*"))):
+    if not os.path.isdir(d):
+        continue
+    # gpurun merges into an existing directory: an earlier run's files may lie beside this run's
+    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
     for r in csv.DictReader(open(f)):
         m = re.search(r"::(\w+)[<(]", r["Kernel_Name"])
         k = m.group(1) if m else r["Kernel_Name"]
