@@ -201,6 +201,37 @@ detect_nms_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__
 // unrolled, and with the image tile staged by aligned 4-byte loads.  Requires
 // 4-byte aligned rows (base, bpl and stream stride multiples of 4); anything
 // else takes the generic kernel above.
+#ifdef VH_EMIT_TIMING
+// debug build only (EXTRA=-DVH_EMIT_TIMING; -DVH_EMIT_TIMING=2 puts the clocks into detect_nms_fast instead): s_memtime
+// ticks the workgroups spent per phase, summed over workgroups.  emit_features: [0] prefix [1] phase A [2] A2 row ranks
+// [3] bin slots + staging [4] phase B; detect_nms_fast: [0] image tile [1] filters [2] block extrema [3] window checks
+// [4] records; [5] workgroups;
+// [6] earliest start, [7] latest end (one launch between two resets)
+__device__ unsigned long long g_emit_t[8];
+extern "C" int32_t vh_debug_emit_timing(unsigned long long *out, int32_t reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_emit_t), sizeof(g_emit_t)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[8] = {0}; z[6] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_emit_t), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+// (one workgroup in 61 carries the clocks: same-address atomics from every workgroup would be the longest phase)
+#define VH_TICK_IMPL(k) do { __syncthreads(); if (t_on_) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_emit_t[k], now_ - t_prev_); t_prev_ = now_; if ((k) == 4) atomicMax(&g_emit_t[7], now_); } } while (0)
+#define VH_TICK_INIT_IMPL const bool t_on_ = threadIdx.x == 0 && (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % 61 == 0; unsigned long long t_prev_ = __builtin_readcyclecounter(); if (t_on_) { atomicAdd(&g_emit_t[5], 1ull); atomicMin(&g_emit_t[6], t_prev_); }
+#endif
+#if defined(VH_EMIT_TIMING) && VH_EMIT_TIMING == 2
+#define VH_DTICK(k) VH_TICK_IMPL(k)
+#define VH_DTICK_INIT VH_TICK_INIT_IMPL
+#else
+#define VH_DTICK(k) do { } while (0)
+#define VH_DTICK_INIT do { } while (0)
+#endif
+#if defined(VH_EMIT_TIMING) && VH_EMIT_TIMING != 2
+#define VH_ETICK(k) VH_TICK_IMPL(k)
+#define VH_ETICK_INIT VH_TICK_INIT_IMPL
+#else
+#define VH_ETICK(k) do { } while (0)
+#define VH_ETICK_INIT do { } while (0)
+#endif
+
 template <int N> struct DetTile {
   static constexpr int N1 = N + 1, TBX = 32, TBY = 8;
   static constexpr int FW = TBX * N1 + 2 * N, FH = TBY * N1 + 2 * N;
@@ -209,29 +240,34 @@ template <int N> struct DetTile {
   static constexpr int OFF = (VH_MARGIN - 2) & 3;
   static constexpr int DW = (IW + 3 + 3) / 4;  // dwords per staged row (room for the alignment offset)
   static constexpr int IP = DW * 4;
-  // The filter pass works on groups of 4 response columns that start at a staged dword: column cx is
-  // column OFF + cx of the staged row and of the response rows (pitch FP, int16).
-  static constexpr int G = (FW + OFF + 3) / 4;
-  static constexpr int FP = 4 * G;
-  // a lane filters one group over ROWS consecutive rows after 4 rows of run-in; SEG = number of row
-  // segments, picked for the shortest pass PER WAVE (then the fewest waves): a workgroup's four
-  // waves sit on the four SIMDs of its CU, and a pass that keeps only two of them busy loads two
-  // SIMDs with everybody's filter pass -- the fewest wave instructions in total (3 segments, 2
-  // waves) measured 410 us per S = 256 launch, the balanced choice (7 segments, 4 waves) 387 us.
-  static constexpr int seg_cost(int s) {
-    const int rows = (FH + s - 1) / s, waves = (G * s + 63) / 64;
-    return G * s > 256 ? (1 << 30) : 1000 * ((rows + 4) * 28 + rows * 26) + waves;
+  // The filter pass works on groups of PX = 2 or 4 adjacent response columns, two per register: column
+  // cx is column OFF + cx of the staged row and of the response rows (pitch FP, int16).  A lane
+  // filters one group over ROWS consecutive rows after 4 rows of run-in, SEG = number of row
+  // segments.  PX and SEG are picked for the shortest pass PER WAVE (then the fewest waves): a
+  // workgroup's four waves sit on the four SIMDs of its CU, and a pass that keeps only two of them
+  // busy loads two SIMDs with everybody's filter pass -- at nms_n = 2 the fewest wave instructions
+  // in total (PX 4, 3 segments, 2 waves) measured 410 us per S = 256 launch, the balanced PX 4
+  // layout (9 segments) 387 us.  Instruction costs per row and lane: row pass 28 (PX 4: 7 permutes,
+  // 14 adds) or 18 (PX 2: 5 permutes, 8 adds), column pass 26 or 13.
+  static constexpr int groups(int px) { return (FW + OFF + px - 1) / px; }
+  static constexpr int seg_cost(int px, int s) {
+    const int rows = (FH + s - 1) / s, waves = (groups(px) * s + 63) / 64;
+    const int hrow = px == 4 ? 28 : 18, vrow = px == 4 ? 26 : 13;
+    return groups(px) * s > 256 || rows * (s - 1) >= FH ? (1 << 30) : 1000 * ((rows + 4) * hrow + rows * vrow) + waves;
   }
-  static constexpr int best_seg() {
+  static constexpr int best_seg(int px) {
     int b = 1;
     for (int s = 2; s <= 16; s++)
-      if (seg_cost(s) < seg_cost(b)) b = s;
+      if (seg_cost(px, s) < seg_cost(px, b)) b = s;
     return b;
   }
-  static constexpr int SEG = best_seg();
+  static constexpr int PX = seg_cost(2, best_seg(2)) < seg_cost(4, best_seg(4)) ? 2 : 4;
+  static constexpr int G = groups(PX);
+  static constexpr int FP = PX * G;
+  static constexpr int SEG = best_seg(PX);
   static constexpr int ROWS = (FH + SEG - 1) / SEG;
   static constexpr int BIAS = 8192;  // stored responses are f + BIAS (positive int16; the NMS only compares)
-  static_assert(G + 1 <= DW, "a group reads its own and the next staged dword");
+  static_assert((G - 1) * PX / 4 + 1 <= DW - 1, "a group reads the staged dword it starts in and the next one");
   static_assert(G * SEG <= 256, "one lane per (group, row segment)");
   static constexpr int LAST = FH - (SEG - 1) * ROWS;  // rows of the last segment
   static_assert(LAST >= 1, "every segment has rows");
@@ -255,52 +291,80 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   const int32_t fx0 = VH_MARGIN + bx0 * N1, fy0 = VH_MARGIN + by0 * N1;
   const int32_t ix0 = fx0 - 2, iy0 = fy0 - 2;
   const int32_t ax0 = ix0 - T::OFF;  // a multiple of 4 (DetTile::OFF)
+  VH_DTICK_INIT;
 
-  // 1. stage the image tile with aligned dword loads (zero outside the image)
-  for (int32_t k = tid; k < T::IH * T::DW; k += 256) {
-    const int32_t r = k / T::DW, c = k - r * T::DW;
-    const int32_t gy = iy0 + r, gx = ax0 + 4 * c;
-    uint32_t v = 0;
-    if (gy < g.Hm && gx < g.bplm) v = *(const uint32_t *)(I + (int64_t)gy * g.bplm + gx);
-    ((uint32_t *)sI)[k] = v;
+  // 1. stage the image tile with aligned dword loads (zero outside the image).  All loads of a lane
+  //    are issued before the first is stored: as a rolled load-store loop this stage was 4 dependent
+  //    HBM round trips and 40 % of a workgroup's life.  Out-of-image dwords are loaded from a clamped
+  //    (valid) address and zeroed afterwards, so that no load sits behind a branch.
+  {
+    constexpr int NLD = (T::IH * T::DW + 255) / 256;
+    uint32_t stg[NLD];
+    bool inside[NLD];
+#pragma unroll
+    for (int32_t i = 0; i < NLD; i++) {
+      const int32_t k = min(tid + 256 * i, T::IH * T::DW - 1);
+      const int32_t r = k / T::DW, c = k - r * T::DW;
+      const int32_t gy = iy0 + r, gx = ax0 + 4 * c;
+      stg[i] = *(const uint32_t *)(I + (int64_t)min(gy, g.Hm - 1) * g.bplm + min(gx, g.bplm - 4));
+      inside[i] = gy < g.Hm && gx < g.bplm;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler pairs each load with its store again)
+#pragma unroll
+    for (int32_t i = 0; i < NLD; i++) {
+      const int32_t k = tid + 256 * i;
+      if (k < T::IH * T::DW) ((uint32_t *)sI)[k] = inside[i] ? stg[i] : 0u;
+    }
   }
   __syncthreads();
 
-  // 2. blob / checkerboard responses, four columns per lane and two columns per register: the row
+  VH_DTICK(0);
+  // 2. blob / checkerboard responses, PX columns per lane and two columns per register: the row
   //    sums live in the 16-bit halves of a dword and are added with plain 32-bit adds (full-rate
   //    instructions; every field stays in [0, 65535] through every intermediate, so no carry or
   //    borrow crosses the halves).  f2 = (1,1,0,-1,-1)^T (x) (1,1,0,-1,-1) (filter.cpp:339-347,
   //    :365-367), f1 = -S5x5 + 2*S3x3 + 7*centre (filter.cpp:461-463); both are stored + BIAS.
-  //    Per row and lane: one 8-byte LDS read, 7 byte permutes (the pairs (b_k, b_k+1) of the 8
-  //    bytes) and 14 adds for the row sums of 4 columns, ~26 instructions for the column pass and
-  //    one 8-byte store per plane -- about a third of one-column-per-lane with byte loads.
+  //    Per row and lane: one 8-byte LDS read, byte permutes for the pairs (b_k, b_k+1) of the
+  //    staged bytes and adds for the row sums, then the column pass and one store per plane --
+  //    about a third of one-column-per-lane with byte loads.
   if (tid < T::G * T::SEG) {
+    constexpr int PX = T::PX, NR = PX / 2;
     const int32_t seg = tid / T::G, gq = tid - seg * T::G;
     const int32_t r0 = seg * T::ROWS;
     {
       constexpr uint32_t HB = 512u * 0x00010001u, KB = (uint32_t)T::BIAS * 0x00010001u;
-      const uint32_t *p = (const uint32_t *)sI + r0 * T::DW + gq;
-      uint32_t *o1 = (uint32_t *)sF1 + (r0 * T::FP + 4 * gq) / 2, *o2 = (uint32_t *)sF2 + (r0 * T::FP + 4 * gq) / 2;
-      // rolling state per register (index 0: columns 0,1 of the group; 1: columns 2,3)
-      uint32_t h5[2][5], h3[2][5], pc[2][4], cc[2][5], hcp[2], S5[2] = {0u, 0u};
+      const uint32_t *p = (const uint32_t *)sI + r0 * T::DW + (gq * PX) / 4;
+      // PX 2: a group starts at byte 0 or 2 of its staged dword
+      const uint32_t sel0 = 0x0c010c00u + ((PX == 2 && (gq & 1)) ? 0x00020002u : 0u);
+      uint32_t *o1 = (uint32_t *)sF1 + (r0 * T::FP + PX * gq) / 2, *o2 = (uint32_t *)sF2 + (r0 * T::FP + PX * gq) / 2;
+      // rolling state per register (register 0: columns 0,1 of the group; 1: columns 2,3)
+      uint32_t h5[NR][5], h3[NR][5], pc[NR][4], cc[NR][5], hcp[NR], S5[NR];
+#pragma unroll
+      for (int32_t h = 0; h < NR; h++) S5[h] = 0u;
 #pragma unroll
       for (int32_t t = 0; t < T::ROWS + 4; t++) {
         if (t - 4 < T::LAST || r0 + t - 4 < T::FH) {  // only the last segment can be short
           const uint32_t A = p[t * T::DW], B = p[t * T::DW + 1];
-          // pk = bytes (k, k+1) of the 8 staged bytes, zero-extended to the halves
-          const uint32_t p0 = __builtin_amdgcn_perm(B, A, 0x0c010c00u), p1 = __builtin_amdgcn_perm(B, A, 0x0c020c01u),
-                         p2 = __builtin_amdgcn_perm(B, A, 0x0c030c02u), p3 = __builtin_amdgcn_perm(B, A, 0x0c040c03u),
-                         p4 = __builtin_amdgcn_perm(B, A, 0x0c050c04u), p5 = __builtin_amdgcn_perm(B, A, 0x0c060c05u),
-                         p6 = __builtin_amdgcn_perm(B, A, 0x0c070c06u);
-          const uint32_t a01 = p0 + p1, a23 = p2 + p3, a34 = p3 + p4, a56 = p5 + p6;
-          uint32_t n5[2], n3[2], nc[2], nz[2];
-          n3[0] = a23 + p1;           n3[1] = a34 + p5;             // b+c+d
-          n5[0] = n3[0] + p0 + p4;    n5[1] = n3[1] + p2 + p6;      // a+b+c+d+e
-          nc[0] = (a01 + HB) - a34;   nc[1] = (a23 + HB) - a56;     // a+b-d-e + 512
-          nz[0] = p2;                 nz[1] = p4;                   // c
-          uint32_t f1[2], f2[2];
+          // pk = bytes (k, k+1) of the group's staged bytes, zero-extended to the halves
+          uint32_t pk[PX + 3];
 #pragma unroll
-          for (int32_t h = 0; h < 2; h++) {
+          for (int32_t k = 0; k < PX + 3; k++) pk[k] = __builtin_amdgcn_perm(B, A, sel0 + (uint32_t)k * 0x00010001u);
+          uint32_t n5[NR], n3[NR], nc[NR], nz[NR];
+          if (PX == 4) {
+            const uint32_t a01 = pk[0] + pk[1], a23 = pk[2] + pk[3], a34 = pk[3] + pk[4], a56 = pk[5] + pk[6];
+            n3[0] = a23 + pk[1];             n3[NR - 1] = a34 + pk[5];                   // b+c+d
+            n5[0] = n3[0] + pk[0] + pk[4];   n5[NR - 1] = n3[NR - 1] + pk[2] + pk[6];    // a+b+c+d+e
+            nc[0] = (a01 + HB) - a34;        nc[NR - 1] = (a23 + HB) - a56;              // a+b-d-e + 512
+            nz[0] = pk[2];                   nz[NR - 1] = pk[4];                         // c
+          } else {
+            n3[0] = pk[1] + pk[2] + pk[3];
+            n5[0] = n3[0] + pk[0] + pk[4];
+            nc[0] = ((pk[0] + pk[1]) + HB) - (pk[3] + pk[4]);
+            nz[0] = pk[2];
+          }
+          uint32_t f1[NR], f2[NR];
+#pragma unroll
+          for (int32_t h = 0; h < NR; h++) {
             // slots 0..4 = staged rows t-4..t, the 5-row window of response row t-4
             const uint32_t old5 = h5[h][0];  // row t-5
 #pragma unroll
@@ -320,14 +384,20 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
             }
           }
           if (t >= 4) {
-            *(uint2 *)(o1 + (t - 4) * (T::FP / 2)) = make_uint2(f1[0], f1[1]);
-            *(uint2 *)(o2 + (t - 4) * (T::FP / 2)) = make_uint2(f2[0], f2[1]);
+            if (PX == 4) {
+              *(uint2 *)(o1 + (t - 4) * (T::FP / 2)) = make_uint2(f1[0], f1[NR - 1]);
+              *(uint2 *)(o2 + (t - 4) * (T::FP / 2)) = make_uint2(f2[0], f2[NR - 1]);
+            } else {
+              o1[(t - 4) * (T::FP / 2)] = f1[0];
+              o2[(t - 4) * (T::FP / 2)] = f2[0];
+            }
           }
         }
       }
     }
   }
   __syncthreads();  // responses complete; the image tile is dead from here on
+  VH_DTICK(1);
 
   // 3. NMS (Neubeck/Van Gool alg. 4, matcher.cpp:381-466).  The dominance test
   //    "no strictly smaller value in the (2n+1)^2 window outside the block"
@@ -410,6 +480,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
     }
   }
   __syncthreads();
+  VH_DTICK(2);
   {
     // waves 0-1 check the minima, waves 2-3 the maxima.  Tiles that do not touch
     // the high-side clipping limits (almost all) address the window relative to
@@ -466,6 +537,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
     else { if (unclipped) check(std::false_type{}, std::true_type{}); else check(std::false_type{}, std::false_type{}); }
   }
   __syncthreads();
+  VH_DTICK(3);
   uint32_t codes[4];
   {
     const uint2 cw = ((const uint2 *)sCode)[tid];
@@ -490,6 +562,7 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
   }
   __syncthreads();
   if (tid < 16 && sChunk[tid]) atomicAdd(&chunk_count[(int64_t)id * g.nchunks + chunk_lo + tid], sChunk[tid]);
+  VH_DTICK(4);
 }
 
 // ------------------------------------------------------------- emit_features
@@ -510,22 +583,6 @@ __device__ __forceinline__ int32_t wave_incl_scan(int32_t v) {
 __constant__ int8_t c_desc_dx[16] = {-3, -3, -1, -1, +3, +3, +1, +1, -1, -1, +1, +1, -5, -5, +5, +5};
 __constant__ int8_t c_desc_dy[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5, +5, -3, +3, -3, +3};
 
-#ifdef VH_EMIT_TIMING
-// debug build only (EXTRA=-DVH_EMIT_TIMING): s_memtime ticks workgroups of emit_features spent per phase,
-// summed over workgroups: [0] prefix [1] phase A [2] A2 row ranks [3] bin slots + staging [4] phase B [5] workgroups;
-// [6] earliest start, [7] latest end (one launch between two resets)
-__device__ unsigned long long g_emit_t[8];
-extern "C" int32_t vh_debug_emit_timing(unsigned long long *out, int32_t reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_emit_t), sizeof(g_emit_t)) != hipSuccess) return -3;
-  if (reset) { unsigned long long z[8] = {0}; z[6] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_emit_t), z, sizeof(z)) != hipSuccess) return -3; }
-  return 0;
-}
-#define VH_ETICK(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_emit_t[k], now_ - t_prev_); t_prev_ = now_; if ((k) == 4) atomicMax(&g_emit_t[7], now_); } } while (0)
-#define VH_ETICK_INIT unsigned long long t_prev_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) { atomicAdd(&g_emit_t[5], 1ull); atomicMin(&g_emit_t[6], t_prev_); }
-#else
-#define VH_ETICK(k) do { } while (0)
-#define VH_ETICK_INIT do { } while (0)
-#endif
 
 #ifndef VH_EMIT_NF
 #define VH_EMIT_NF 2
