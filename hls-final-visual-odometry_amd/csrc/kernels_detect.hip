@@ -740,25 +740,30 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const int32_t prk = min(k, 14) - 7;                    // patch row this lane fetches (lane 15: row 14 again, no branch)
   const int32_t rd0 = (dy + 5) * 4 + ((dx + 5) >> 2);         // first dword of the lane's window in a patch
   const uint32_t psel = 0x03020100u + (uint32_t)((dx + 5) & 3) * 0x01010101u;  // v_perm selector of its first four bytes there
-  for (int32_t f0 = 0; f0 < total; f0 += 16 * NF) {
-    int32_t fs[NF], us[NF], vs[NF], cs[NF];
-    bool lives[NF];
-    uint32_t lo[NF][5], hi[NF][5];
-    uint32_t sel[NF];
-    typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
-    u32x4a1 prow[NF];
+  // The patch rows of trip i+1 are in flight while trip i is handed round, computed and stored
+  // (one 16-byte load per lane and feature: 8 registers for the double buffer).
+  typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+  struct Coords { int32_t fs[NF], us[NF], vs[NF], cs[NF]; bool lives[NF]; };
+  auto fetch = [&](int32_t f0, Coords &q, u32x4a1 (&prow)[NF]) {
 #pragma unroll
     for (int32_t h = 0; h < NF; h++) {
-      fs[h] = f0 + 16 * h + grp;
-      lives[h] = fs[h] < total;
-      const uint32_t e = sList[lives[h] ? fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
-      us[h] = e & 0x3FFF; vs[h] = (e >> 14) & 0x3FFF; cs[h] = e >> 28;
-      sel[h] = psel;
+      q.fs[h] = f0 + 16 * h + grp;
+      q.lives[h] = q.fs[h] < total;
+      const uint32_t e = sList[q.lives[h] ? q.fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
+      q.us[h] = e & 0x3FFF; q.vs[h] = (e >> 14) & 0x3FFF; q.cs[h] = e >> 28;
       if (ALIGNED) {
         // 32-bit byte offsets from the (wave-uniform) image base: images are < 2^28 bytes, rows < 2^14
-        prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(us[h] - 7)));
+        prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(q.vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(q.us[h] - 7)));
       }
     }
+  };
+  auto process = [&](const Coords &q, const u32x4a1 (&prow)[NF]) {
+    const int32_t *fs = q.fs, *us = q.us, *vs = q.vs, *cs = q.cs;
+    const bool *lives = q.lives;
+    uint32_t lo[NF][5], hi[NF][5];
+    uint32_t sel[NF];
+#pragma unroll
+    for (int32_t h = 0; h < NF; h++) sel[h] = psel;
     if (ALIGNED) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -825,6 +830,22 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
       const bool okf = lives[h] && fi < cap;
       if (okf && k < 12) out[(int64_t)fi * 12 + k] = (int32_t)word;
       if (okf && k == 12) fuv[fi] = (uint32_t)(u << sh) | ((uint32_t)(v << sh) << 16);
+    }
+  };
+  // two register sets, taken in turns: a copy from "next" to "current" would have to wait for the loads
+  if (total > 0) {
+    Coords qa, qb;
+    u32x4a1 pa[NF], pb[NF];
+    fetch(0, qa, pa);
+    for (int32_t f0 = 0;; f0 += 32 * NF) {  // all conditions are workgroup-uniform
+      const bool more1 = f0 + 16 * NF < total;
+      if (more1) fetch(f0 + 16 * NF, qb, pb);
+      process(qa, pa);
+      if (!more1) break;
+      const bool more2 = f0 + 32 * NF < total;
+      if (more2) fetch(f0 + 32 * NF, qa, pa);
+      process(qb, pb);
+      if (!more2) break;
     }
   }
   VH_ETICK(4);
