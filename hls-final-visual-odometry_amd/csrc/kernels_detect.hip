@@ -595,8 +595,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   int32_t *__restrict__ count = s.count;
   const int32_t cap = s.cap;
   __shared__ uint32_t sList[4 * VH_CHUNK + 1];  // u | v<<14 | c<<28 (matching-resolution coords); last word = sink for empty slots
-  __shared__ int32_t sWave[4];
-  __shared__ int32_t sBase;
+  __shared__ int32_t sWave[4], sWaveP[4];
 
   const int32_t id = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const uint8_t *__restrict__ I = vh_image_ptr(im, id);
@@ -604,36 +603,36 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const int32_t n1 = g.n + 1;
   VH_ETICK_INIT;
 
+  // phase A: each lane owns VH_CHUNK/256 consecutive blocks; the four 16-bit codes of a
+  // block are handled as two dwords so every extract is one 32-bit op.  The records and the
+  // counts of the earlier chunks are requested together (one memory round trip, not two), from
+  // clamped addresses so that no load sits behind a branch.
+  constexpr int BPL = VH_CHUNK / 256;  // consecutive blocks per lane
+  uint32_t clo[BPL], chi[BPL];
+  {
+    const uint2 *rp = reinterpret_cast<const uint2 *>(rec) + (int64_t)id * g.nblocks;
+#pragma unroll
+    for (int32_t k = 0; k < BPL; k++) {
+      const uint2 c = rp[min(chunk * VH_CHUNK + tid * BPL + k, g.nblocks - 1)];
+      clo[k] = c.x; chi[k] = c.y;
+    }
+  }
   // features emitted by earlier chunks of this image
   int32_t part = 0;
   for (int32_t k = tid; k < chunk; k += 256) part += chunk_count[(int64_t)id * g.nchunks + k];
-#pragma unroll
-  for (int32_t d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
-  if ((tid & 63) == 0) sWave[tid >> 6] = part;
-  __syncthreads();
-  if (tid == 0) sBase = sWave[0] + sWave[1] + sWave[2] + sWave[3];
-  __syncthreads();
-  const int32_t base = sBase;
-  __syncthreads();
-  VH_ETICK(0);
-
-  // phase A: each lane owns VH_CHUNK/256 consecutive blocks; the four 16-bit codes of a
-  // block are handled as two dwords so every extract is one 32-bit op
-  constexpr int BPL = VH_CHUNK / 256;  // consecutive blocks per lane
-  uint32_t clo[BPL], chi[BPL];
   int32_t mine = 0;
 #pragma unroll
   for (int32_t k = 0; k < BPL; k++) {
-    const int32_t blk = chunk * VH_CHUNK + tid * BPL + k;
-    uint2 c = make_uint2(~0u, ~0u);
-    if (blk < g.nblocks) c = reinterpret_cast<const uint2*>(rec)[(int64_t)id * g.nblocks + blk];
-    clo[k] = c.x;
-    chi[k] = c.y;
-    mine += ((c.x & 0xFFFFu) != VH_NO_CODE) + ((c.x >> 16) != VH_NO_CODE) + ((c.y & 0xFFFFu) != VH_NO_CODE) + ((c.y >> 16) != VH_NO_CODE);
+    if (chunk * VH_CHUNK + tid * BPL + k >= g.nblocks) clo[k] = chi[k] = ~0u;
+    mine += ((clo[k] & 0xFFFFu) != VH_NO_CODE) + ((clo[k] >> 16) != VH_NO_CODE) + ((chi[k] & 0xFFFFu) != VH_NO_CODE) + ((chi[k] >> 16) != VH_NO_CODE);
   }
+#pragma unroll
+  for (int32_t d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
   const int32_t incl = wave_incl_scan(mine);
-  if ((tid & 63) == 63) sWave[tid >> 6] = incl;
+  if ((tid & 63) == 63) { sWave[tid >> 6] = incl; sWaveP[tid >> 6] = part; }
   __syncthreads();
+  const int32_t base = sWaveP[0] + sWaveP[1] + sWaveP[2] + sWaveP[3];
+  VH_ETICK(0);
   int32_t woff = 0;
   for (int32_t w = 0; w < (tid >> 6); w++) woff += sWave[w];
   const int32_t total = sWave[0] + sWave[1] + sWave[2] + sWave[3];
@@ -664,6 +663,31 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   __syncthreads();
   if (chunk == g.nchunks - 1 && tid == 0) count[set] = base + total;
   VH_ETICK(1);
+  // (phase B's lane roles, here because its first patch loads are requested now, ahead of phase A2)
+  const int32_t grp = tid >> 4, k = tid & 15;
+  const int32_t dx = c_desc_dx[k], dy = c_desc_dy[k];
+  constexpr int NF = VH_EMIT_NF;  // features per lane group and trip
+  const int32_t prk = min(k, 14) - 7;                    // patch row this lane fetches (lane 15: row 14 again, no branch)
+  // The patch rows of trip i+1 are in flight while trip i is handed round, computed and stored
+  // (one 16-byte load per lane and feature: 8 registers for the double buffer).
+  typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+  struct Coords { int32_t fs[NF], us[NF], vs[NF], cs[NF]; bool lives[NF]; };
+  auto fetch = [&](int32_t f0, Coords &q, u32x4a1 (&prow)[NF]) {
+#pragma unroll
+    for (int32_t h = 0; h < NF; h++) {
+      q.fs[h] = f0 + 16 * h + grp;
+      q.lives[h] = q.fs[h] < total;
+      const uint32_t e = sList[q.lives[h] ? q.fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
+      q.us[h] = e & 0x3FFF; q.vs[h] = (e >> 14) & 0x3FFF; q.cs[h] = e >> 28;
+      if (ALIGNED) {
+        // 32-bit byte offsets from the (wave-uniform) image base: images are < 2^28 bytes, rows < 2^14
+        prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(q.vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(q.us[h] - 7)));
+      }
+    }
+  };
+  Coords qa, qb;
+  u32x4a1 pa[NF], pb[NF];
+  if (total > 0) fetch(0, qa, pa);
 
   // phase A2: bin histogram + per-bin staging + row histogram, one lane per
   // feature.  Kept out of the descriptor loop below: a returning atomic inside
@@ -681,6 +705,19 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const int32_t v_span = ((blk_last / g.nbx) * n1 + g.n + VH_MARGIN + g.n) * g.scale + g.scale - v_first;  // ... and one past the largest, relative
   const bool rows_in_lds = v_span <= ROWS_LDS;
   int32_t *__restrict__ rowh = s.row_hist + (int64_t)set * 4 * s.H;
+  // createIndexVector's bin of a feature (matcher.cpp:208-212)
+  auto bin_of_entry = [&](uint32_t e) {
+    const int32_t uu = (int32_t)(e & 0x3FFF) * g.scale, vv = (int32_t)((e >> 14) & 0x3FFF) * g.scale, c = e >> 28;
+    const int32_t ubin = s.binsize == 1 ? uu : (int32_t)__umulhi((uint32_t)uu, s.inv_binsize);
+    const int32_t vbin = s.binsize == 1 ? vv : (int32_t)__umulhi((uint32_t)vv, s.inv_binsize);
+    return (c * s.ubn + min(ubin, s.ubn - 1)) * s.vbn + min(vbin, s.vbn - 1);
+  };
+  // The bin slot of the lane's first feature is requested here, ahead of the row ranks: the two
+  // returning atomics of a feature are then one round trip deep, not two.
+  const bool have0 = tid < total && base + tid < cap;
+  const int32_t b0 = have0 ? bin_of_entry(sList[tid]) : 0;
+  int32_t slot0 = 0;
+  if (have0) slot0 = atomicAdd(&s.hist[(int64_t)set * s.nbins + b0], 1);
   if (rows_in_lds) {
     // (a) count the chunk's features per row in LDS, remembering each one's rank in its row;
     // (b) one returning global atomic per row that occurs reserves the chunk's range of the
@@ -705,12 +742,10 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     const int32_t fi = base + f;
     if (fi >= cap) break;
     const uint32_t e = sList[f];
-    const int32_t uu = (int32_t)(e & 0x3FFF) * g.scale, vv = (int32_t)((e >> 14) & 0x3FFF) * g.scale, c = e >> 28;
-    const int32_t ubin = s.binsize == 1 ? uu : (int32_t)__umulhi((uint32_t)uu, s.inv_binsize);
-    const int32_t vbin = s.binsize == 1 ? vv : (int32_t)__umulhi((uint32_t)vv, s.inv_binsize);
-    const int32_t b = (c * s.ubn + min(ubin, s.ubn - 1)) * s.vbn + min(vbin, s.vbn - 1);
+    const int32_t vv = (int32_t)((e >> 14) & 0x3FFF) * g.scale, c = e >> 28;
+    const int32_t b = f == tid ? b0 : bin_of_entry(e);
     const int32_t rowrel = rows_in_lds ? sRow[c * ROWS_LDS + (vv - v_first)] + (int32_t)sLoc[f] : atomicAdd(&rowh[c * s.H + vv], 1);
-    const int32_t slot = atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
+    const int32_t slot = f == tid ? slot0 : atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
     if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = make_int2(fi, rowrel);
   }
 
@@ -724,8 +759,6 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   // feature, plus the rows that straddle a line -- and handed round through LDS, from where every
   // lane takes its five row segments at offsets that depend on the lane alone.  A lane group
   // lives inside one wave and a wave's LDS instructions execute in order: no barrier is needed.
-  const int32_t grp = tid >> 4, k = tid & 15;
-  const int32_t dx = c_desc_dx[k], dy = c_desc_dy[k];
   const int32_t sh = g.scale - 1;  // scale is 1 or 2
   int32_t *__restrict__ out = feat + (int64_t)set * cap * 12;
   uint32_t *__restrict__ fuv = s.f_uv + (int64_t)set * cap;
@@ -733,30 +766,11 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const int32_t gbase = (tid & 63) & ~15, j = (k >= 4) ? (k - 4) : 0;
   // (branch-free word select: the lane's role is loop-invariant; word 2, val, is zeroed on packing, matcher.cpp:667)
   const uint32_t m_u = k == 0 ? ~0u : 0u, m_v = k == 1 ? ~0u : 0u, m_c = k == 3 ? ~0u : 0u, m_d = k >= 4 ? ~0u : 0u;
-  constexpr int NF = VH_EMIT_NF;  // features per lane group and trip
   static_assert(16 * NF * 16 * 16 <= (int)sizeof(sLoc), "the patches reuse sLoc");
   __syncthreads();  // sLoc is dead from here on
   uint32_t *sPatch = (uint32_t *)sLoc + grp * (NF * 64);  // [feature of the trip][16 rows: 15 + lane 15's spare][4 dwords] of this lane group
-  const int32_t prk = min(k, 14) - 7;                    // patch row this lane fetches (lane 15: row 14 again, no branch)
   const int32_t rd0 = (dy + 5) * 4 + ((dx + 5) >> 2);         // first dword of the lane's window in a patch
   const uint32_t psel = 0x03020100u + (uint32_t)((dx + 5) & 3) * 0x01010101u;  // v_perm selector of its first four bytes there
-  // The patch rows of trip i+1 are in flight while trip i is handed round, computed and stored
-  // (one 16-byte load per lane and feature: 8 registers for the double buffer).
-  typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
-  struct Coords { int32_t fs[NF], us[NF], vs[NF], cs[NF]; bool lives[NF]; };
-  auto fetch = [&](int32_t f0, Coords &q, u32x4a1 (&prow)[NF]) {
-#pragma unroll
-    for (int32_t h = 0; h < NF; h++) {
-      q.fs[h] = f0 + 16 * h + grp;
-      q.lives[h] = q.fs[h] < total;
-      const uint32_t e = sList[q.lives[h] ? q.fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
-      q.us[h] = e & 0x3FFF; q.vs[h] = (e >> 14) & 0x3FFF; q.cs[h] = e >> 28;
-      if (ALIGNED) {
-        // 32-bit byte offsets from the (wave-uniform) image base: images are < 2^28 bytes, rows < 2^14
-        prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(q.vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(q.us[h] - 7)));
-      }
-    }
-  };
   auto process = [&](const Coords &q, const u32x4a1 (&prow)[NF]) {
     const int32_t *fs = q.fs, *us = q.us, *vs = q.vs, *cs = q.cs;
     const bool *lives = q.lives;
@@ -834,9 +848,6 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   };
   // two register sets, taken in turns: a copy from "next" to "current" would have to wait for the loads
   if (total > 0) {
-    Coords qa, qb;
-    u32x4a1 pa[NF], pb[NF];
-    fetch(0, qa, pa);
     for (int32_t f0 = 0;; f0 += 32 * NF) {  // all conditions are workgroup-uniform
       const bool more1 = f0 + 16 * NF < total;
       if (more1) fetch(f0 + 16 * NF, qb, pb);
