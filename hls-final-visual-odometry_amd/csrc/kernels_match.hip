@@ -512,7 +512,6 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
   const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
   const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
-  const int32_t *__restrict__ cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
 
   bool valid[Q];
   uint4 a0[Q], a1[Q];
