@@ -44,13 +44,14 @@ struct Group {
   vh_params p{};
   int32_t device = 0, S = 1;
   int32_t req_features = 0, req_matches = 0;
-  // Two internal streams: detection+indexing of frame t+1 overlaps the matching
+  // Internal streams: detection+indexing of frame t+1 overlaps the matching
   // of frame t (the ring has three slots for that).  `stream` is the detect
   // stream (also used by the stateless paths); a caller-owned stream, if set,
   // only orders our work after the caller's (image producers).
-  // A third stream takes the short, latency-bound post-processing (chain +
-  // emission) of frame t, so that the flow search of frame t+1 follows that of
-  // frame t back to back; the match tables are double-buffered for that.
+  // A third stream (default; VH_POST_STREAM=0: the match stream) takes the short,
+  // latency-bound post-processing (chain + emission) of frame t, so that the flow
+  // search of frame t+1 follows that of frame t back to back; the match tables are
+  // double-buffered for that.
   hipStream_t own_stream = nullptr, stream = nullptr, match_stream = nullptr, post_stream = nullptr, user_stream = nullptr;
   hipEvent_t ev_tables[2] = {nullptr, nullptr};  // match tables of buffer b complete
   hipEvent_t ev_post[2] = {nullptr, nullptr};    // post-processing finished reading buffer b

@@ -7,25 +7,31 @@
 //                                          src/matcher.cpp:470-514)
 //   the packing loop of computeFeatures   (reference src/matcher.cpp:663-671)
 //
-// Design (integer work, no MFMA; VALU/LDS-issue bound):
+// Design (integer work, no MFMA; see DESIGN.md section 4 for what bounds each kernel):
 //   detect_nms    one workgroup per tile of 32x8 NMS blocks: the image tile
-//                 (+halo) is staged in LDS once, the blob and checkerboard
-//                 responses are produced into LDS by a separable sliding-window
-//                 pass and never touch HBM; NMS runs on the LDS tile: block
+//                 (+halo) is staged in LDS once (all loads of a lane in one
+//                 batch), the blob and checkerboard responses are produced into
+//                 LDS and never touch HBM; NMS runs on the LDS tile: block
 //                 extrema and threshold per lane, then, for the queued few
 //                 that passed it, "candidate == minimum of its clipped
 //                 (2n+1)^2 window" -- equivalent to the reference's
 //                 per-candidate dominance scan -- and leaves 8 bytes per block
 //                 (4 x u16 position codes).
 //                 detect_nms_fast<N> (nms_n 1..4, 4-byte aligned rows) is the
-//                 compile-time specialised form; detect_nms_kernel is the
-//                 generic one (any nms_n, any stride) with the literal scan.
+//                 compile-time specialised form: filters on packed 16-bit row
+//                 sums, 2 or 4 columns per lane, responses stored + 8192; block
+//                 extrema by packed min/max when nms_n is odd.
+//                 detect_nms_kernel is the generic one (any nms_n, any stride)
+//                 with one column per lane and the literal scan.
 //   emit_features ordered compaction of those codes (reference output order:
-//                 block row-major, class ascending), bin/row histograms and
-//                 per-bin staging (first half of createIndexVector), then the
-//                 32-byte descriptor of each survivor is computed straight from
-//                 the image (16 lanes per feature, one sample point each): the
-//                 Sobel planes the reference materialises are never written.
+//                 block row-major, class ascending), bin slots and (class, v)
+//                 row ranks (first half of createIndexVector), then the
+//                 32-byte descriptor of each survivor is computed from its
+//                 15x15 image patch (fetched once, shared through LDS; 16 lanes
+//                 per feature, one sample point each): the Sobel planes the
+//                 reference materialises are never written.
+//   Debug builds: -DVH_EMIT_TIMING[=2] puts phase clocks into emit_features
+//                 [detect_nms_fast] (tools/emit_timing.py).
 #include "vh_dev.h"
 #include <type_traits>
 
