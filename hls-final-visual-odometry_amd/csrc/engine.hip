@@ -4,7 +4,7 @@
 // A vh_group owns S independent camera streams that are stepped together; a
 // vh_matcher is a group of one.  The reference's Matcher state (ring buffer of
 // two feature-set pairs, src/matcher.h:245-259) lives in HBM and rotates by
-// moving the current/previous roles between three slots; nothing is copied on pushBack.
+// moving the current/previous roles between the slots of a ring; nothing is copied on pushBack.
 #include "vh_dev.h"
 #include "../../include/viso_hip.h"
 
@@ -20,6 +20,16 @@
 #include <vector>
 
 namespace {
+
+// Ring slots per stream.  Three are the minimum for detecting frame t+1 while frame t is matched
+// against t-1 -- but then the detection of t+2 overwrites the slot of t-1 and has to wait for the
+// emission of match t, and the search of t+2 for that detection: both chains idle ~6 % of a step
+// (rocprofv3 timeline, KITTI, S = 256).  With four, detection runs a whole frame ahead and neither
+// stream waits for the other.  VH_RING=3 rebuilds the old ring.
+#ifndef VH_RING
+#define VH_RING 4
+#endif
+static_assert(VH_RING >= 3 && VH_RING <= 8, "ring slots");
 
 thread_local std::string t_last_error;
 
@@ -45,7 +55,7 @@ struct Group {
   int32_t device = 0, S = 1;
   int32_t req_features = 0, req_matches = 0;
   // Internal streams: detection+indexing of frame t+1 overlaps the matching
-  // of frame t (the ring has three slots for that).  `stream` is the detect
+  // of frame t (the ring has VH_RING slots for that).  `stream` is the detect
   // stream (also used by the stateless paths); a caller-owned stream, if set,
   // only orders our work after the caller's (image producers).
   // A third stream (default; VH_POST_STREAM=0: the match stream) takes the short,
@@ -72,9 +82,9 @@ struct Group {
   int32_t stats_slot = 0, probe_countdown = 0, force_mode = -1;
   bool spec_mode = true;
   double last_redo_rate = -1;
-  hipEvent_t ev_det[3] = {nullptr, nullptr, nullptr};   // slot fully detected + indexed
-  hipEvent_t ev_read[3] = {nullptr, nullptr, nullptr};  // last match that read the slot
-  bool ev_read_valid[3] = {false, false, false};
+  hipEvent_t ev_det[VH_RING] = {};   // slot fully detected + indexed
+  hipEvent_t ev_read[VH_RING] = {};  // last match that read the slot
+  bool ev_read_valid[VH_RING] = {};
   hipEvent_t ev_user = nullptr;
   bool user_stream_set = false;  // handle 0 is a real stream (the legacy default stream): "unset" is a flag, not a value
   bool failed = false;           // the last push did not complete: no matching until the next successful one
@@ -129,7 +139,7 @@ struct Group {
 
   ~Group() {
     release();
-    for (int k = 0; k < 3; k++) { if (ev_det[k]) (void)hipEventDestroy(ev_det[k]); if (ev_read[k]) (void)hipEventDestroy(ev_read[k]); }
+    for (int k = 0; k < VH_RING; k++) { if (ev_det[k]) (void)hipEventDestroy(ev_det[k]); if (ev_read[k]) (void)hipEventDestroy(ev_read[k]); }
     if (ev_user) (void)hipEventDestroy(ev_user);
     for (int k = 0; k < 2; k++) if (ev_stage[k]) (void)hipEventDestroy(ev_stage[k]);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -244,7 +254,7 @@ struct Group {
       sets.stage_cap = (int32_t)std::min<int64_t>(per_axis * per_axis, cap);
     }
     sets.tile_span = (2 * p.match_radius >= dims[1]) ? sets.ubn * sets.vbn : sets.vbn;
-    const size_t ns = 6 * (size_t)S;  // 3 ring slots x (left, right) per stream
+    const size_t ns = 2 * VH_RING * (size_t)S;  // ring slots x (left, right) per stream
     if ((rc = dmalloc(&sets.feat, ns * cap * 12, false))) return rc;
     if ((rc = dmalloc(&sets.f_uv, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.s_uv, ns * cap, false))) return rc;
@@ -282,10 +292,10 @@ struct Group {
     allocated = true;
     pair_cur = 0; pair_prev = 1; frames = 0; epoch = 0; last_method = -1; failed = false;
     host_matches.assign((size_t)S, {}); host_filtered.assign((size_t)S, 0);
-    for (int k = 0; k < 3; k++) ev_read_valid[k] = false;
+    for (int k = 0; k < VH_RING; k++) ev_read_valid[k] = false;
     ev_post_valid[0] = ev_post_valid[1] = false; match_seq = 0;
     // every slot starts "detected" (empty): matches may wait on any of them
-    for (int k = 0; k < 3; k++) VH_HIP(hipEventRecord(ev_det[k], stream));
+    for (int k = 0; k < VH_RING; k++) VH_HIP(hipEventRecord(ev_det[k], stream));
     return VH_OK;
   }
 
@@ -348,8 +358,8 @@ struct Group {
 
   int32_t push_device_queued(const void *dI1, const void *dI2, int64_t stride, const int32_t d[3], int32_t replace) {
     int32_t rc = VH_OK;
-    if (!replace && frames > 0) {  // ring buffer shift (matcher.cpp:64-79): prev <- cur, cur <- the third slot
-      const int32_t fresh = 3 - pair_cur - pair_prev;
+    if (!replace && frames > 0) {  // ring buffer shift (matcher.cpp:64-79): prev <- cur, cur <- the slot used longest ago
+      const int32_t fresh = (pair_cur + 1) % VH_RING;
       pair_prev = pair_cur;
       pair_cur = fresh;
     }
@@ -592,7 +602,7 @@ struct Group {
   int32_t get_counts(int32_t *nf, int32_t *nm) {
     if (!allocated) return VH_ERR_STATE;
     if (nf) {
-      std::vector<int32_t> all(6 * (size_t)S);
+      std::vector<int32_t> all(2 * VH_RING * (size_t)S);
       VH_HIP(hipMemcpyAsync(all.data(), sets.count, sizeof(int32_t) * all.size(), hipMemcpyDeviceToHost, stream));
       VH_HIP(hipStreamSynchronize(stream));
       for (int32_t s = 0; s < S; s++)
@@ -819,7 +829,7 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
   for (int k = 0; k < 2 && ok; k++)
     ok = hipEventCreateWithFlags(&gq->ev_tables[k], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&gq->ev_post[k], hipEventDisableTiming) == hipSuccess;
-  for (int k = 0; k < 3 && ok; k++)
+  for (int k = 0; k < VH_RING && ok; k++)
     ok = hipEventCreateWithFlags(&gq->ev_det[k], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&gq->ev_read[k], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&gq->ev_user, hipEventDisableTiming) == hipSuccess;
