@@ -593,7 +593,6 @@ __constant__ int8_t c_desc_dy[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5,
 #ifndef VH_EMIT_NF
 #define VH_EMIT_NF 2
 #endif
-template <bool ALIGNED>
 __global__ void __launch_bounds__(256)
 emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
                      const int32_t *__restrict__ chunk_count, VhSets s) {
@@ -685,10 +684,9 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
       q.lives[h] = q.fs[h] < total;
       const uint32_t e = sList[q.lives[h] ? q.fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
       q.us[h] = e & 0x3FFF; q.vs[h] = (e >> 14) & 0x3FFF; q.cs[h] = e >> 28;
-      if (ALIGNED) {
-        // 32-bit byte offsets from the (wave-uniform) image base: images are < 2^28 bytes, rows < 2^14
-        prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(q.vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(q.us[h] - 7)));
-      }
+      // 32-bit byte offsets from the (wave-uniform) image base: images are <= 2^28 bytes, rows < 2^14, strides
+      // < 2^24.  Byte-granular: no alignment of the image or its stride is assumed.  u+8 <= W-1 for every feature.
+      prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(q.vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(q.us[h] - 7)));
     }
   };
   Coords qa, qb;
@@ -784,62 +782,43 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     uint32_t sel[NF];
 #pragma unroll
     for (int32_t h = 0; h < NF; h++) sel[h] = psel;
-    if (ALIGNED) {
-      __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int32_t h = 0; h < NF; h++)
-        *(uint4 *)(sPatch + (h * 16 + k) * 4) = make_uint4(prow[h].x, prow[h].y, prow[h].z, prow[h].w);
+    for (int32_t h = 0; h < NF; h++)
+      *(uint4 *)(sPatch + (h * 16 + k) * 4) = make_uint4(prow[h].x, prow[h].y, prow[h].z, prow[h].w);
 #pragma unroll
-      for (int32_t h = 0; h < NF; h++)
+    for (int32_t h = 0; h < NF; h++)
 #pragma unroll
-        for (int32_t r = 0; r < 5; r++) {
-          lo[h][r] = sPatch[h * 64 + rd0 + 4 * r];
-          hi[h][r] = sPatch[h * 64 + rd0 + 4 * r + 1];
-        }
-    }
+      for (int32_t r = 0; r < 5; r++) {
+        lo[h][r] = sPatch[h * 64 + rd0 + 4 * r];
+        hi[h][r] = sPatch[h * 64 + rd0 + 4 * r + 1];
+      }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int32_t h = 0; h < NF; h++) {
       const int32_t u = us[h], v = vs[h];
       // 5x5 Sobel pair at (u+dx, v+dy): du = smooth_y (x) deriv_x, dv = deriv_y (x) smooth_x
       // (filter.cpp:288-318 column pass, :132-171 / :79-127 row passes)
-      int32_t a_du = 0, a_dv = 0;
-      if (ALIGNED) {
-        // With w = bytes x0..x0+3 and w' = bytes x0+1..x0+4 of a row, its sums are byte dot products
-        // (v_dot4_u32_u8, accumulating): a+2b-2d-e = w.(1,2,0,0) - w'.(0,0,2,1) and
-        // a+4b+6c+4d+e = w.(1,4,6,0) + w'.(0,0,4,1); the column weights (1,4,6,4,1) resp.
-        // (1,2,0,-2,-1) are folded into the byte weights, positive and negative parts apart.
-        uint32_t du_p = 0, du_n = 0, dv_p = 0, dv_n = 0;
+      // With w = bytes x0..x0+3 and w' = bytes x0+1..x0+4 of a row, its sums are byte dot products
+      // (v_dot4_u32_u8, accumulating): a+2b-2d-e = w.(1,2,0,0) - w'.(0,0,2,1) and
+      // a+4b+6c+4d+e = w.(1,4,6,0) + w'.(0,0,4,1); the column weights (1,4,6,4,1) resp.
+      // (1,2,0,-2,-1) are folded into the byte weights, positive and negative parts apart.
+      uint32_t du_p = 0, du_n = 0, dv_p = 0, dv_n = 0;
 #pragma unroll
-        for (int32_t r = 0; r < 5; r++) {
-          const uint32_t w = __builtin_amdgcn_perm(hi[h][r], lo[h][r], sel[h]);
-          const uint32_t w1 = __builtin_amdgcn_perm(hi[h][r], lo[h][r], sel[h] + 0x01010101u);
-          const uint32_t sw = (r == 0 || r == 4) ? 1u : (r == 2 ? 6u : 4u);
-          du_p = __builtin_amdgcn_udot4(w, sw * 0x00000201u, du_p, false);
-          du_n = __builtin_amdgcn_udot4(w1, sw * 0x01020000u, du_n, false);
-          if (r != 2) {
-            const uint32_t dw = (r == 0 || r == 4) ? 1u : 2u;
-            uint32_t &acc = r < 2 ? dv_p : dv_n;
-            acc = __builtin_amdgcn_udot4(w, dw * 0x00060401u, acc, false);
-            acc = __builtin_amdgcn_udot4(w1, dw * 0x01040000u, acc, false);
-          }
-        }
-        a_du = (int32_t)(du_p - du_n);
-        a_dv = (int32_t)(dv_p - dv_n);
-      } else {
-        const uint8_t *p = I + (int64_t)(v + dy - 2) * g.bplm + (u + dx - 2);
-#pragma unroll
-        for (int32_t r = 0; r < 5; r++) {
-          const int32_t a = p[0], b = p[1], cc = p[2], dd = p[3], ee = p[4];
-          const int32_t rowD = a + 2 * b - 2 * dd - ee;
-          const int32_t rowS = a + 4 * b + 6 * cc + 4 * dd + ee;
-          const int32_t sw = (r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4);
-          const int32_t dw = (r == 0) ? 1 : (r == 1 ? 2 : (r == 2 ? 0 : (r == 3 ? -2 : -1)));
-          a_du += sw * rowD;
-          a_dv += dw * rowS;
-          p += g.bplm;
+      for (int32_t r = 0; r < 5; r++) {
+        const uint32_t w = __builtin_amdgcn_perm(hi[h][r], lo[h][r], sel[h]);
+        const uint32_t w1 = __builtin_amdgcn_perm(hi[h][r], lo[h][r], sel[h] + 0x01010101u);
+        const uint32_t sw = (r == 0 || r == 4) ? 1u : (r == 2 ? 6u : 4u);
+        du_p = __builtin_amdgcn_udot4(w, sw * 0x00000201u, du_p, false);
+        du_n = __builtin_amdgcn_udot4(w1, sw * 0x01020000u, du_n, false);
+        if (r != 2) {
+          const uint32_t dw = (r == 0 || r == 4) ? 1u : 2u;
+          uint32_t &acc = r < 2 ? dv_p : dv_n;
+          acc = __builtin_amdgcn_udot4(w, dw * 0x00060401u, acc, false);
+          acc = __builtin_amdgcn_udot4(w1, dw * 0x01040000u, acc, false);
         }
       }
+      const int32_t a_du = (int32_t)(du_p - du_n), a_dv = (int32_t)(dv_p - dv_n);
       // arithmetic >>7, +128, unsigned saturation (filter.cpp:114-115,124 / :159-160,168)
       const uint32_t du = (uint32_t)min(255, max(0, (a_du >> 7) + 128));
       const uint32_t dv = (uint32_t)min(255, max(0, (a_dv >> 7) + 128));
@@ -942,10 +921,7 @@ void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t
                              const int32_t *chunk_count, const VhSets &s, hipStream_t st) {
   if (g.nblocks <= 0) return;
   dim3 grid(g.nchunks, im.S * im.ncam);
-  if (images_dword_aligned(im, g))
-    hipLaunchKernelGGL(emit_features_kernel<true>, grid, dim3(256), 0, st, im, g, rec, chunk_count, s);
-  else
-    hipLaunchKernelGGL(emit_features_kernel<false>, grid, dim3(256), 0, st, im, g, rec, chunk_count, s);
+  hipLaunchKernelGGL(emit_features_kernel, grid, dim3(256), 0, st, im, g, rec, chunk_count, s);
 }
 
 void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
