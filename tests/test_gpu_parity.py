@@ -84,9 +84,27 @@ def test_known_answers_full_size(case, pkg, oracle, gpu):
     assert pm[:32].tobytes() == z[case + "__head_p_match"].tobytes()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
+def test_every_filter_layout_of_detect_nms(n, pkg, ob, oracle, gpu):
+    """detect_nms_fast<N> lays its filter pass out per nms_n (2 or 4 columns per lane, 3..7 row
+    segments; packed block extrema for odd n) and nms_n = 5 takes the generic kernel: each layout
+    on an image of several tiles with partial edge tiles, on a smooth and on a tie-rich texture."""
+    W, H = 777, 301
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    for blur, gain, tau in ((6, 1, 50), (2, 3, 20)):
+        img = pkg.synth.frame(W, H, 3, 1, blur, gain, 40 + n)
+        if gain == 3:  # flat and saturated patches: equal responses, first-in-scan-order ties
+            img = img.copy(); img[40:90, 100:260] = 255; img[150:200, 300:520] = 17
+        p, po = pkg.Params.default(nms_n=n, nms_tau=tau), ob.Params.default(nms_n=n, nms_tau=tau)
+        got = pkg.compute_features(p, img, dims)
+        want = oracle.compute_features(po, img, dims)
+        assert len(want[1]) > 200 and np.array_equal(got[1], want[1]), (n, blur, gain, tau)
+
+
 def test_unaligned_stride_generic_kernels(pkg, ob, oracle, gpu):
     """Rows that do not start on 4-byte boundaries (bpl = odd width, as the
-    reference's dims[2] >= dims[0] contract allows) take the byte-load kernels."""
+    reference's dims[2] >= dims[0] contract allows) take the generic detection kernel
+    (emit_features fetches its patches byte-granular either way)."""
     rng = np.random.default_rng(3)
     for W, H, n in ((201, 100, 2), (333, 121, 3), (255, 97, 6)):
         img = pkg.synth.frame(W, H, blur=3, seed=W)[:, :W].copy()  # stride == W
