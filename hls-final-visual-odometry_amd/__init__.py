@@ -24,6 +24,7 @@ from . import synth  # noqa: F401  (synthetic KITTI-shaped frames)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VISO_HIP_LIB") or os.path.join(HERE, "libviso_hip.so")  # override: experiment builds
+CHECK_LIB_PATH = os.path.join(HERE, "libviso_hip_check.so")  # the -DVH_CHECK build (tests only)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
@@ -98,9 +99,12 @@ class VisoHipError(RuntimeError):
 
 
 def build(verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into libviso_hip.so (in-tree)."""
+    """Compile every HIP source for gfx950 into libviso_hip.so (in-tree), and the -DVH_CHECK
+    variant libviso_hip_check.so (index invariants verified on the device, csrc/vh_dev.h) that
+    tests/ run a part of the suite on."""
     cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
     subprocess.check_call(cmd)
+    subprocess.check_call(cmd + ["VARIANT=check"])
     return LIB_PATH
 
 

@@ -68,7 +68,7 @@ struct Group {
   bool ev_post_valid[2] = {false, false};
   int64_t match_seq = 0;
   int32_t *d_mchunk = nullptr;   // [S][cap/256] survivors per emission chunk, followed by the 2 statistics words of the launch
-  int32_t *d_redo = nullptr;     // [S] queries the speculative searches had to search again (reset by emit_matches)
+  int32_t *d_redo = nullptr;     // [2][S] queries the speculative searches had to search again, per table buffer (reset by emit_matches)
   // Loop policy of the searches (match()): speculative (no accept test in the loop, the winner
   // verified, failures searched again) or tested.  The speculative loop is ~12 % faster when
   // almost every query's best candidate lies inside its window (0.5 % re-searched on the
@@ -157,6 +157,24 @@ struct Group {
     VH_HIP(hipStreamSynchronize(match_stream));
     VH_HIP(hipStreamSynchronize(post_stream));
     VH_HIP(hipStreamSynchronize(down_stream));
+    return check_violation();
+  }
+  // -DVH_CHECK builds: the kernels verify the index invariants they otherwise trust (vh_dev.h,
+  // VH_CHECK_RANGE) and record the first violation; the host aborts at the next point where it
+  // waits for the device anyway.  The shipped build compiles this to nothing.
+  int32_t check_violation() {
+#ifdef VH_CHECK
+    if (allocated && sets.check) {
+      uint32_t c[4] = {0, 0, 0, 0};
+      VH_HIP(hipDeviceSynchronize());
+      VH_HIP(hipMemcpy(c, sets.check, sizeof(c), hipMemcpyDeviceToHost));
+      if (c[0]) {
+        fprintf(stderr, "VH_CHECK: %u index violations; first: code %u, value %d, bound %d (codes: vh_dev.h)\n", c[0], c[1], (int)c[2], (int)c[3]);
+        fflush(stderr);
+        abort();
+      }
+    }
+#endif
     return VH_OK;
   }
 
@@ -170,6 +188,7 @@ struct Group {
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr; d_redo = nullptr;
     stats_pending[0] = stats_pending[1] = false;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
+    d_ego_rand = nullptr; d_ego_ok = nullptr; d_ego_xyz = nullptr; d_ego_tr = nullptr; ego_rand_n = 0;
     if (h_overflow) { (void)hipHostFree(h_overflow); h_overflow = nullptr; }
     allocated = false;
   }
@@ -230,6 +249,8 @@ struct Group {
     if (allocated) { int32_t rs = sync_all(); if (rs) return rs; release(); }
     if (d[0] <= 0 || d[1] <= 0 || d[2] < d[0]) return VH_ERR_INVALID_ARG;
     if (d[0] > 16384 || d[1] > 16384) return VH_ERR_UNSUPPORTED;
+    // emit_features addresses its patch rows with 24 x 24 -> 32-bit byte offsets from the image base
+    if (d[2] >= (1 << 24) || (int64_t)d[2] * d[1] > (1ll << 28)) return VH_ERR_UNSUPPORTED;
     int32_t rc = setup_geometry(d);
     if (rc != VH_OK) return rc;
     dims[0] = d[0]; dims[1] = d[1]; dims[2] = d[2];
@@ -273,6 +294,7 @@ struct Group {
     if ((rc = dmalloc(&sets.r_pos, ns * cap, false))) return rc;
     if ((rc = dmalloc(&sets.tiles, ns * sets.max_tiles, false))) return rc;
     if ((rc = dmalloc(&sets.tile_cnt, ns, true))) return rc;
+    if ((rc = dmalloc(&sets.check, 4, true))) return rc;
     if ((rc = dmalloc(&d_rec, 2 * (size_t)S * std::max(g.nblocks, 1), false))) return rc;
     if ((rc = dmalloc(&d_chunk_count, 2 * (size_t)S * g.nchunks, true))) return rc;
     for (int k = 0; k < 2; k++) {
@@ -281,7 +303,7 @@ struct Group {
     }
     d_best = d_best2[0]; d_chain = d_chain2[0];
     if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 255) / 256) + 2, true))) return rc;
-    if ((rc = dmalloc(&d_redo, (size_t)S, true))) return rc;
+    if ((rc = dmalloc(&d_redo, 2 * (size_t)S, true))) return rc;  // one set of counters per match-table buffer: the search of match n+1 runs beside the emission of match n
     if ((rc = dmalloc((uint8_t **)&d_matches, (size_t)S * mcap * sizeof(vh_p_match), false))) return rc;
     if ((rc = dmalloc(&d_match_count, (size_t)S, true))) return rc;
     if ((rc = dmalloc(&d_overflow, (size_t)S, true))) return rc;
@@ -495,7 +517,7 @@ struct Group {
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_prev], 0));
     if (ev_post_valid[buf]) VH_HIP(hipStreamWaitEvent(ms, ev_post[buf], 0));
     const bool spec = choose_loop();
-    { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo, spec ? 1 : 0, ms); }
+    { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo + (size_t)buf * S, spec ? 1 : 0, ms); }
     VH_HIP(hipGetLastError());
     VH_HIP(hipEventRecord(ev_tables[buf], ms));
     VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
@@ -515,7 +537,7 @@ struct Group {
     { Scope sc(this, "chain", ps); vh_launch_chain(sets, a, method, d_best2[buf], d_chain2[buf], d_mask, epoch, d_mchunk, ps); }
     // a download of the previous step's lists may still be reading d_matches
     if (ev_down_valid) VH_HIP(hipStreamWaitEvent(ps, ev_down, 0));
-    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, d_redo, d_mchunk + n_mchunk, ps); }
+    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, d_redo + (size_t)buf * S, d_mchunk + n_mchunk, ps); }
     VH_HIP(hipGetLastError());
     {  // (re-searched, searched) of this launch -> page-locked memory, read by a later choose_loop()
       const int32_t sl = stats_slot; stats_slot ^= 1;
@@ -551,6 +573,7 @@ struct Group {
   int32_t wait_download() {
     if (!ev_down_valid) return VH_OK;
     VH_HIP(hipEventSynchronize(ev_down));
+    { const int32_t rv_ = check_violation(); if (rv_) return rv_; }
     for (int32_t s = 0; s < S; s++) if (h_overflow[s]) return VH_ERR_CAPACITY;
     return VH_OK;
   }
@@ -569,6 +592,7 @@ struct Group {
     VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipMemcpyAsync(&ov, d_overflow + s, sizeof(int32_t), hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipStreamSynchronize(post_stream));
+    { const int32_t rv_ = check_violation(); if (rv_) return rv_; }
     *n = cnt;
     const int32_t k = std::min(std::min(cnt, mcap), capo);
     if (k > 0) {
@@ -626,6 +650,7 @@ struct Group {
     VH_HIP(hipMemcpyAsync(counts, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipStreamSynchronize(post_stream));
+    { const int32_t rv_ = check_violation(); if (rv_) return rv_; }
     bool over = false;
     for (int32_t s = 0; s < S; s++) over = over || h_overflow[s] != 0;
     for (int32_t s = 0; s < S; s++) {
@@ -689,30 +714,39 @@ struct Group {
     return failed ? VH_ERR_INVALID_ARG : VH_OK;
   }
 
-  // VisualOdometryStereo::estimateMotion on the device-resident quad match lists of every stream
+  // VisualOdometryStereo::estimateMotion on the device-resident quad match lists of every stream.
+  // The scratch (random values, 3-d points, results) belongs to the group and only grows: a
+  // hipFree per call would drain the detect/match/post pipeline (it synchronises the device).
+  int32_t *d_ego_rand = nullptr, *d_ego_ok = nullptr;
+  double *d_ego_xyz = nullptr, *d_ego_tr = nullptr;
+  size_t ego_rand_n = 0;
   int32_t estimate_motion(const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok, int32_t *ninl) {
     if (!e || !rand3 || !tr || !ok || !ninl || e->ransac_iters < 1) return VH_ERR_INVALID_ARG;
     if (!allocated || last_method != VH_METHOD_QUAD) return VH_ERR_STATE;
     const size_t nr = (size_t)S * e->ransac_iters * 3;
-    int32_t *d_rand = nullptr, *d_ok = nullptr;
-    double *d_xyz = nullptr, *d_tr = nullptr;
-    // scratch of this call only (hipMalloc/hipFree: a few per frame; the matching itself never allocates)
-    VH_HIP(hipMalloc((void **)&d_rand, sizeof(int32_t) * nr));
-    hipError_t er = hipMalloc((void **)&d_xyz, sizeof(double) * (size_t)S * mcap * 4);
-    if (er == hipSuccess) er = hipMalloc((void **)&d_tr, sizeof(double) * 6 * (size_t)S);
-    if (er == hipSuccess) er = hipMalloc((void **)&d_ok, sizeof(int32_t) * 2 * (size_t)S);
-    if (er == hipSuccess) er = hipMemcpyAsync(d_rand, rand3, sizeof(int32_t) * nr, hipMemcpyHostToDevice, post_stream);
-    if (er == hipSuccess) {
-      vh_launch_ego(*e, S, (const vh_p_match *)d_matches, mcap, nullptr, d_match_count, mcap, d_rand, d_xyz, mcap, d_tr, d_ok, d_ok + S,
-                    nullptr, 0, post_stream);
-      er = hipGetLastError();
+    int32_t rc;
+    if (!d_ego_xyz) {
+      if ((rc = dmalloc(&d_ego_xyz, (size_t)S * mcap * 4, false))) return rc;
+      if ((rc = dmalloc(&d_ego_tr, 6 * (size_t)S, false))) return rc;
+      if ((rc = dmalloc(&d_ego_ok, 2 * (size_t)S, false))) return rc;
     }
-    if (er == hipSuccess) er = hipMemcpyAsync(tr, d_tr, sizeof(double) * 6 * (size_t)S, hipMemcpyDeviceToHost, post_stream);
-    if (er == hipSuccess) er = hipMemcpyAsync(ok, d_ok, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream);
-    if (er == hipSuccess) er = hipMemcpyAsync(ninl, d_ok + S, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream);
-    if (er == hipSuccess) er = hipStreamSynchronize(post_stream);
-    (void)hipFree(d_rand); (void)hipFree(d_xyz); (void)hipFree(d_tr); (void)hipFree(d_ok);
-    if (er != hipSuccess) { t_last_error = hipGetErrorString(er); return VH_ERR_HIP; }
+    if (ego_rand_n < nr) {  // (the old block stays in `allocs` until the group is released: a few KB per change of ransac_iters)
+      if ((rc = dmalloc(&d_ego_rand, nr, false))) return rc;
+      ego_rand_n = nr;
+    }
+    VH_HIP(hipMemcpyAsync(d_ego_rand, rand3, sizeof(int32_t) * nr, hipMemcpyHostToDevice, post_stream));
+    vh_launch_ego(*e, S, (const vh_p_match *)d_matches, mcap, nullptr, d_match_count, mcap, d_ego_rand, d_ego_xyz, mcap, d_ego_tr, d_ego_ok,
+                  d_ego_ok + S, nullptr, 0, post_stream);
+    VH_HIP(hipGetLastError());
+    VH_HIP(hipMemcpyAsync(tr, d_ego_tr, sizeof(double) * 6 * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(ok, d_ego_ok, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(ninl, d_ego_ok + S, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    // a truncated match list or feature set yields a pose of the truncated data: say so, as every get_matches path does
+    std::vector<int32_t> cnt((size_t)S);
+    VH_HIP(hipMemcpyAsync(cnt.data(), d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipStreamSynchronize(post_stream));
+    for (int32_t s = 0; s < S; s++) if (cnt[s] > mcap || h_overflow[s]) return VH_ERR_CAPACITY;
     return VH_OK;
   }
 
@@ -1099,6 +1133,7 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
                                   int32_t *n_inliers, int32_t *inliers) {
   if (!e || n_sets < 1 || !offsets || !rand3 || !tr || !ok || !n_inliers || e->ransac_iters < 1) return VH_ERR_INVALID_ARG;
   int64_t nmax = 0;
+  if (offsets[0] < 0) return VH_ERR_INVALID_ARG;
   for (int32_t s = 0; s < n_sets; s++) {
     if (offsets[s + 1] < offsets[s]) return VH_ERR_INVALID_ARG;
     nmax = std::max<int64_t>(nmax, offsets[s + 1] - offsets[s]);

@@ -175,6 +175,9 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
   const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
   const int32_t p0 = bs[bin], p1 = bs[bin + 1], L = p1 - p0;
   if (L <= 0) return;
+#ifdef VH_CHECK
+  if (staged && gl == 0) { int32_t len = L; VH_CHECK_RANGE(s, 6, len, 0, s.stage_cap + 1); }
+#endif
   // members of this bin, in arbitrary order: staged by emit_features (own features, with
   // their rank in their (class, v) row) or placed by bin_fill (caller-supplied features)
   const int2 *__restrict__ stg = s.stage + ((int64_t)set * s.nbins + bin) * s.stage_cap - p0;
@@ -216,8 +219,9 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
       // matcher minimises a (cost, bin position) key): detected features bring their rank in the
       // row along (emit_features), caller-supplied ones take a ticket here.
       const int32_t row = (int32_t)h.w * s.H + (int32_t)h.y;
-      // (the rank is clamped into the row's range: a corrupt rank must show up as a wrong result, never as a stray write)
-      const int32_t rp = min(rs[row] + (staged ? rowrel : atomicAdd(&rcur[row], 1)), rs[row + 1] - 1);
+      // (ranks within a row are 0 .. count-1, each taken once: emit_features' LDS ranks + reserved offsets, or the cursor)
+      int32_t rp = rs[row] + (staged ? rowrel : atomicAdd(&rcur[row], 1));
+      VH_CHECK_RANGE(s, 4, rp, rs[row], rs[row + 1]);
       rpos[rp] = p;
     }
   }

@@ -750,6 +750,9 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     const int32_t b = f == tid ? b0 : bin_of_entry(e);
     const int32_t rowrel = rows_in_lds ? sRow[c * ROWS_LDS + (vv - v_first)] + (int32_t)sLoc[f] : atomicAdd(&rowh[c * s.H + vv], 1);
     const int32_t slot = f == tid ? slot0 : atomicAdd(&s.hist[(int64_t)set * s.nbins + b], 1);
+#ifdef VH_CHECK
+    { int32_t sl = slot; VH_CHECK_RANGE(s, 5, sl, 0, s.stage_cap); }
+#endif
     if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = make_int2(fi, rowrel);
   }
 

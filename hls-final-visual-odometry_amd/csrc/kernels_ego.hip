@@ -192,7 +192,8 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
     if (k < e.ransac_iters) {
       // getRandomSample(N,3): three draws without replacement from the ordered index list (src/viso.cpp:96-102)
       const int32_t *r = rand3 + ((int64_t)s * e.ransac_iters + k) * 3;
-      int32_t a = r[0] % n, b = r[1] % (n - 1), c = r[2] % (n - 2);
+      // (rand() returns 0 .. RAND_MAX; the sign bit of a caller-supplied value is dropped rather than turned into a negative index)
+      int32_t a = (r[0] & 0x7FFFFFFF) % n, b = (r[1] & 0x7FFFFFFF) % (n - 1), c = (r[2] & 0x7FFFFFFF) % (n - 2);
       b += b >= a ? 1 : 0;
       const int32_t lo = min(a, b), hi = max(a, b);
       c += c >= lo ? 1 : 0;

@@ -412,7 +412,11 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
     redo[qi] = false;
     if (SPEC && valid[qi] && ph == 0 && k != ~0ull) {
       // the winner over the union region: inside this query's own window?
-      const us2 t = as_us2(cuv[pbase + min((int32_t)(uint32_t)k, pcnt - 1)]) - lo2[qi];
+      // (a winner is never one of the copies past the end of a run -- the original has the same SAD at a lower
+      //  position -- so its position lies inside the class)
+      int32_t wp = (int32_t)(uint32_t)k;
+      VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
+      const us2 t = as_us2(cuv[pbase + wp]) - lo2[qi];
       const us2 m = __builtin_elementwise_min(t, span2);
       redo[qi] = as_u32(t) != as_u32(m);
     }
@@ -450,7 +454,9 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
   for (int32_t qi = 0; qi < Q; qi++) {
     if (valid[qi] && ph == 0) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + min((int32_t)(uint32_t)kfin[qi], pcnt - 1)];
+      int32_t wp = (kfin[qi] == ~0ull) ? 0 : (int32_t)(uint32_t)kfin[qi];
+      if (kfin[qi] != ~0ull) VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
+      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + wp];
       best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q0 + L * qi + l]] = r;
     }
   }
@@ -526,7 +532,8 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   for (int32_t qi = 0; qi < Q; qi++) {
     const int32_t q = q0 + L * qi + l;
     valid[qi] = q < q1;
-    qp[qi] = min(max(qpos[valid[qi] ? q : q0], 0), s.cap - 1);  // row order holds bin positions; the records are gathered from the bin-ordered arrays
+    qp[qi] = qpos[valid[qi] ? q : q0];  // row order holds bin positions; the records are gathered from the bin-ordered arrays
+    VH_CHECK_RANGE(s, 1, qp[qi], 0, s.cap);
     uv1[qi] = quv[qp[qi]];
     a0[qi] = qdesc[2 * (int64_t)qp[qi]]; a1[qi] = qdesc[2 * (int64_t)qp[qi] + 1];
     const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
@@ -542,9 +549,10 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   const int32_t r1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + VHI + 1]);
   for (int32_t rc = r0; rc < r1; rc += 64) {
     const int32_t mcnt = min(64, r1 - rc);
-    // slots past the end repeat the last candidate: same key, harmless.  The position is clamped into the class's
-    // range (a corrupt row index must show up as a wrong result, never as a stray access).
-    const int32_t cp = min(max(cpos[min(rc + lane, r1 - 1)], pbase), pbase + pcnt - 1);
+    // slots past the end repeat the last candidate: same key, harmless.  Every slot of the row index in
+    // [row_start[0], row_start[4H]) holds a position of the row's own class (bin_sort writes each exactly once).
+    int32_t cp = cpos[min(rc + lane, r1 - 1)];
+    VH_CHECK_RANGE(s, 2, cp, pbase, pbase + pcnt);
     const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
     uint32_t gu = 0;
     if (!SPEC) gu = cuv[cp];
@@ -585,7 +593,11 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
     kfin[qi] = k;
     redo[qi] = false;
     if (SPEC && valid[qi] && ph == 0 && k != ~0ull) {
-      const us2 t = as_us2(cuv[pbase + min((int32_t)(uint32_t)k, pcnt - 1)]) - lo2[qi];
+      // (a winner is never one of the copies past the end of a run -- the original has the same SAD at a lower
+      //  position -- so its position lies inside the class)
+      int32_t wp = (int32_t)(uint32_t)k;
+      VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
+      const us2 t = as_us2(cuv[pbase + wp]) - lo2[qi];
       const us2 m = __builtin_elementwise_min(t, span2);
       redo[qi] = as_u32(t) != as_u32(m);
     }
@@ -611,7 +623,8 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
       const int32_t x1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + min(v1 + a.disp_tol, s.H - 1) + 1]);
       uint64_t k = ~0ull;
       for (int32_t x = x0 + lane; x < x1; x += 64) {
-        const int32_t cp = min(max(cpos[x], pbase), pbase + pcnt - 1);
+        int32_t cp = cpos[x];
+        VH_CHECK_RANGE(s, 3, cp, pbase, pbase + pcnt);
         k = min(k, tested_key_uniform_query(qd, qlo2, span2, cuv[cp], cdesc[2 * (int64_t)cp], cdesc[2 * (int64_t)cp + 1], (uint32_t)(cp - pbase)));
       }
       k = wave_min_u64(k);
@@ -622,7 +635,9 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   for (int32_t qi = 0; qi < Q; qi++) {
     if (valid[qi] && ph == 0) {
       // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + min((int32_t)(uint32_t)kfin[qi], pcnt - 1)];
+      int32_t wp = (kfin[qi] == ~0ull) ? 0 : (int32_t)(uint32_t)kfin[qi];
+      if (kfin[qi] != ~0ull) VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
+      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + wp];
       best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[qp[qi]]] = r;
     }
   }

@@ -95,7 +95,30 @@ struct VhSets {
   int32_t W, H;      // dims_c of the matcher (full resolution)
   int32_t stage_cap;   // max features of one class in one bin for features of this detector (geometry bound)
   int32_t tile_span; // bins per tile group: vbn (one (class,u-bin) column) or ubn*vbn (a whole class)
+  uint32_t *check;   // [4] -DVH_CHECK builds: {violations, code of the first, its value, its bound}; unused otherwise
 };
+
+// Index invariants of the device-side indices (row index -> bin position -> record).  The shipped
+// build trusts them (no clamps: DESIGN.md section 2a says why each holds); a -DVH_CHECK build
+// verifies every one on the device, records the first violation in VhSets::check and continues with
+// the index forced into range, and the host side aborts the process at the next synchronisation
+// (engine.hip: check_violation) -- loud, but without a wild access on a shared GPU.
+//   codes: 1 rows_tile query position, 2 rows_tile candidate position, 3 row re-search candidate
+//          position, 4 bin_sort row slot, 5 emit_features stage slot, 6 bin_sort staged bin length,
+//          7 winner position of a search
+#ifdef VH_CHECK
+#define VH_CHECK_RANGE(s_, code_, x_, lo_, hi_)                                          \
+  do {                                                                                   \
+    if ((x_) < (lo_) || (x_) >= (hi_)) {                                                 \
+      if (atomicAdd(&(s_).check[0], 1u) == 0u) {                                         \
+        (s_).check[1] = (uint32_t)(code_); (s_).check[2] = (uint32_t)(x_); (s_).check[3] = (uint32_t)(hi_); \
+      }                                                                                  \
+      (x_) = (lo_) < (hi_) ? (((x_) < (lo_)) ? (lo_) : (hi_) - 1) : (lo_);                \
+    }                                                                                    \
+  } while (0)
+#else
+#define VH_CHECK_RANGE(s_, code_, x_, lo_, hi_) do { } while (0)
+#endif
 
 struct VhPass {
   int32_t qset;  // role (VH_SET_*) providing the queries

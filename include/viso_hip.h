@@ -95,7 +95,8 @@ void vh_default_params(vh_params *p);
 /* Matcher::Matcher(parameters) (src/matcher.cpp:32-41) on HIP device `device`.
  * Envelope (VH_ERR_UNSUPPORTED outside): 1 <= nms_n <= 32, match_binsize >= 1,
  * 0 <= match_radius <= 16384, 0 <= match_disp_tolerance <= 16384, nms_tau >= 0,
- * images up to 16384 x 16384.  max_features/max_matches = 0 select the
+ * images up to 16384 x 16384 with a row pitch dims[2] < 2^24 bytes and dims[2]*dims[1] <= 2^28
+ * bytes.  max_features/max_matches = 0 select the
  * worst-case capacity for the pushed image size (4 per NMS block), clamped to
  * 16 777 215 features per image.
  * When a pushed image yields more features than the capacity, the records

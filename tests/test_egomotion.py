@@ -136,3 +136,24 @@ def test_gpu_group_estimate_motion_on_device_matches(pkg, ob, oracle, gpu):
         ok_o, tr_o, inl_o = oracle.estimate_motion_stereo(e, pm, oracle.draw_samples(len(pm), 200, raw[s].reshape(-1)))
         assert ok[s] == ok_o and ninl[s] == len(inl_o) and _close(tr[s], tr_o), (s, tr[s], tr_o)
     g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_estimate_motion_rejects_hostile_inputs(pkg, ob, oracle, gpu):
+    """Public C-ABI inputs reach the device validated: rand3 values with the sign bit set index like
+    their low 31 bits (never a negative match index), a negative first offset is refused."""
+    import ctypes as C
+    e = ego_params(ob, ransac_iters=64)
+    ge = pkg.EgoParams(ransac_iters=64, reweighting=1, inlier_threshold=2.0, f=e.f, cu=e.cu, cv=e.cv, base=e.base)
+    pm = scene(ob.P_MATCH_DTYPE, 200, 77, outliers=0.2, noise=0.2)[0]
+    raw = np.random.default_rng(9).integers(0, 2 ** 31 - 1, (1, 64, 3)).astype(np.int32)
+    neg = (raw | np.int32(-2 ** 31)).astype(np.int32)  # every value negative
+    tr_a, ok_a, inl_a = pkg.estimate_motion_stereo(ge, [pm], raw)
+    tr_b, ok_b, inl_b = pkg.estimate_motion_stereo(ge, [pm], neg)
+    assert ok_a[0] == ok_b[0] and np.array_equal(inl_a[0], inl_b[0]) and tr_a.tobytes() == tr_b.tobytes()
+    offsets = np.array([-1, len(pm) - 1], np.int32)
+    tr = np.zeros(6); ok = np.zeros(1, np.int32); ninl = np.zeros(1, np.int32)
+    rc = pkg._lib().vh_estimate_motion_stereo(C.byref(ge), 0, 1, pm.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p),
+                                              raw.ctypes.data_as(C.c_void_p), tr.ctypes.data_as(C.c_void_p), ok.ctypes.data_as(C.c_void_p),
+                                              ninl.ctypes.data_as(C.c_void_p), None)
+    assert rc == pkg.VH_ERR_INVALID_ARG

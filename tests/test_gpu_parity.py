@@ -432,8 +432,11 @@ def test_1080p_all_classes_radius200(pkg, ob, oracle, gpu):
         assert np.array_equal(a, b)
     assert min(len(x) for x in f) > 30000 and len(got) > 20000
     assert set(np.unique(f[2][:, 3])) == {0, 1, 2, 3}
-    _check_match_properties(pkg, oracle, po, dims, f, got, 2, np.random.default_rng(1), 300)
-    # exact table check for one whole pass (the oracle needs ~1 s for it)
+    # the whole p_match list of the quad match, byte for byte (the oracle needs ~1 s for it at this size)
+    want = oracle.matching(po, dims, 2, *want_f)
+    assert len(want) == len(got) and got.tobytes() == want.tobytes()
+    _check_match_properties(pkg, oracle, po, dims, f, got, 2, np.random.default_rng(1), 50)
+    # ... and one whole findMatch table
     assert np.array_equal(pkg.match_all(pkg.Params.default(), dims, f[2], f[3], flow=False),
                           oracle.match_all(po, dims, f[2], f[3], flow=False))
 
@@ -456,7 +459,9 @@ def test_4k_dense_small_bins(pkg, ob, oracle, gpu):
     assert np.array_equal(fc, oracle.compute_features(po, Ic, dims)[1])
     assert len(fc) > 100000 and len(got) > 80000
     f = [fp, np.zeros((0, 12), np.int32), fc, np.zeros((0, 12), np.int32)]
-    _check_match_properties(pkg, oracle, po, dims, f, got, 0, np.random.default_rng(2), 200)
+    want = oracle.matching(po, dims, 0, fp, f[1], fc, f[3])  # the whole flow p_match list (~4 s of oracle time)
+    assert len(want) == len(got) and got.tobytes() == want.tobytes()
+    _check_match_properties(pkg, oracle, po, dims, f, got, 0, np.random.default_rng(2), 50)
     assert np.mean((got["u1p"] - got["u1c"] == 5) & (got["v1p"] - got["v1c"] == 1)) > 0.9
     # no pixel of the current image is matched twice (mask M)
     pix = got["v1c"].astype(np.int64) * W + got["u1c"].astype(np.int64)
@@ -544,6 +549,23 @@ def test_flow_search_tested_loop_path(gpu):
 
 
 @pytest.mark.gpu
+def test_index_invariants_on_the_checking_build(pkg, gpu):
+    """libviso_hip_check.so (-DVH_CHECK) verifies on the device every index the shipped kernels
+    use unclamped -- row index -> bin position -> record, stage slots, winner positions
+    (csrc/vh_dev.h: VH_CHECK_RANGE) -- and aborts the process on the first violation.  The parity
+    cases that exercise those indices, the truncated-set case (features > capacity) among them,
+    must pass on it: same results, no violation."""
+    import subprocess, sys
+    assert os.path.exists(pkg.CHECK_LIB_PATH), "build() makes it"
+    env = dict(os.environ, VISO_HIP_LIB=pkg.CHECK_LIB_PATH)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "golden or random_configs or tie_break or ring_buffer or kitti or overflow or async_download or dims_change"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "VH_CHECK" not in r.stderr
+
+
+@pytest.mark.gpu
 def test_group_get_matches_all(pkg, ob, oracle, gpu):
     """vh_group_get_matches_all == per-stream vh_group_get_matches, also after the
     host-side outlier vote and into a page-locked buffer."""
@@ -606,6 +628,19 @@ def test_group_async_download(pkg, ob, oracle, gpu):
         want = oracle.matching(po, dims, 2, F[s][tt - 1][0], F[s][tt - 1][1], F[s][tt][0], F[s][tt][1])
         assert cnts[b][s] == len(want) and bufs[b][s, :len(want)].tobytes() == want.tobytes()
     g.close()
+
+
+@pytest.mark.gpu
+def test_row_pitch_beyond_the_envelope_is_refused(pkg, gpu):
+    """emit_features addresses patch rows with 32-bit byte offsets (strides < 2^24, images <= 2^28
+    bytes): a larger pitch is VH_ERR_UNSUPPORTED, not silently truncated offsets."""
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
+    img = np.zeros((8, 64), np.uint8)
+    for dims in ([64, 8, 1 << 24], [64, 8192, 1 << 16]):
+        d = (C.c_int32 * 3)(*dims)
+        rc = pkg._lib().vh_push_back(m._h, img.ctypes.data_as(C.c_void_p), None, d, 0)  # refused before any byte is read
+        assert rc == pkg.VH_ERR_UNSUPPORTED, dims
+    m.close()
 
 
 # ------------------------------------------------ round 2: the bench's own entry points, stream ordering, overflow
@@ -691,7 +726,9 @@ def test_4k_stereo_quad_small_bins(pkg, ob, oracle, gpu):
     assert min(len(x) for x in f) > 100000 and len(got) > 80000
     assert np.array_equal(pkg.match_all(p, dims, f[0], f[1], flow=False), oracle.match_all(po, dims, f[0], f[1], flow=False))
     assert np.array_equal(pkg.match_all(p, dims, f[3], f[2], flow=False), oracle.match_all(po, dims, f[3], f[2], flow=False))
-    _check_match_properties(pkg, oracle, po, dims, f, got, 2, np.random.default_rng(4), 200)
+    want = oracle.matching(po, dims, 2, *want_f)  # the whole quad p_match list, byte for byte (~3 s of oracle time)
+    assert len(want) == len(got) and got.tobytes() == want.tobytes()
+    _check_match_properties(pkg, oracle, po, dims, f, got, 2, np.random.default_rng(4), 50)
     ok = (got["u1p"] - got["u2p"] == 14) & (got["u1c"] - got["u2c"] == 14)
     assert ok.mean() > 0.9
 
@@ -719,7 +756,9 @@ def test_4k_dense_maxima_beyond_the_old_envelope(pkg, ob, oracle, gpu):
     assert np.array_equal(fc, oracle.compute_features(po, Ic, dims)[1])
     assert np.array_equal(pkg.match_all(p, dims, fc, fp, flow=False), oracle.match_all(po, dims, fc, fp, flow=False))
     f = [fp, np.zeros((0, 12), np.int32), fc, np.zeros((0, 12), np.int32)]
-    _check_match_properties(pkg, oracle, po, dims, f, got, 0, np.random.default_rng(8), 300)
+    want = oracle.matching(po, dims, 0, fp, f[1], fc, f[3])  # > 10^6 flow matches, byte for byte (~12 s of oracle time)
+    assert len(want) == len(got) and got.tobytes() == want.tobytes()
+    _check_match_properties(pkg, oracle, po, dims, f, got, 0, np.random.default_rng(8), 50)
     assert len(got) > 300000
     pix = got["v1c"].astype(np.int64) * W + got["u1c"].astype(np.int64)
     assert len(np.unique(pix)) == len(pix)
