@@ -44,6 +44,7 @@ ABI_SYMBOLS = (
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_clear_stream", "vh_group_stream_wait_images", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset",
     "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion", "vh_group_search_stats",
+    "vh_default_mono_params", "vh_estimate_motion_mono", "vh_group_estimate_motion_mono",
 )
 
 
@@ -75,6 +76,21 @@ class EgoParams(C.Structure):
     @classmethod
     def default(cls, **kw):
         e = cls(ransac_iters=200, reweighting=1, inlier_threshold=2.0, f=1.0, cu=0.0, cv=0.0, base=1.0)
+        for k, v in kw.items():
+            if not hasattr(e, k):
+                raise AttributeError(k)
+            setattr(e, k, v)
+        return e
+
+
+class MonoParams(C.Structure):
+    """VisualOdometryMono::parameters + calibration (reference src/viso_mono.h:32-46, src/viso.h:41-50)."""
+    _fields_ = [("ransac_iters", C.c_int32), ("reserved_", C.c_int32), ("inlier_threshold", C.c_double), ("motion_threshold", C.c_double),
+                ("height", C.c_double), ("pitch", C.c_double), ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double)]
+
+    @classmethod
+    def default(cls, **kw):
+        e = cls(ransac_iters=2000, reserved_=0, inlier_threshold=0.00001, motion_threshold=100.0, height=1.0, pitch=0.0, f=1.0, cu=0.0, cv=0.0)
         for k, v in kw.items():
             if not hasattr(e, k):
                 raise AttributeError(k)
@@ -151,6 +167,8 @@ def _lib():
             "vh_group_profile_reset": [vp],
             "vh_estimate_motion_stereo": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
             "vh_group_estimate_motion": [vp, vp, vp, vp, vp, vp],
+            "vh_estimate_motion_mono": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+            "vh_group_estimate_motion_mono": [vp, vp, vp, vp, vp, vp],
             "vh_group_search_stats": [vp, vp, vp],
         }
         for name, args in sig.items():
@@ -422,6 +440,15 @@ class StreamGroup:
         _check(_lib().vh_group_estimate_motion(self._h, C.byref(ego), _ptr(rand3), _ptr(tr), _ptr(ok), _ptr(ninl)), "vh_group_estimate_motion")
         return tr, ok.astype(bool), ninl
 
+    def estimateMotionMono(self, mono: "MonoParams", rand8):
+        """VisualOdometryMono::estimateMotion (reference src/viso_mono.cpp:41-160) on every stream's device-resident
+        flow (or quad) matches; rand8 [S, ransac_iters, 8] int32 rand() values -> (tr [S,6], ok [S], n_inliers [S])."""
+        rand8 = np.ascontiguousarray(rand8, np.int32)
+        assert rand8.shape == (self.S, mono.ransac_iters, 8)
+        tr = np.zeros((self.S, 6), np.float64); ok = np.zeros(self.S, np.int32); ninl = np.zeros(self.S, np.int32)
+        _check(_lib().vh_group_estimate_motion_mono(self._h, C.byref(mono), _ptr(rand8), _ptr(tr), _ptr(ok), _ptr(ninl)), "vh_group_estimate_motion_mono")
+        return tr, ok.astype(bool), ninl
+
     def searchStats(self):
         """-> (speculative loops in use?, last observed share of re-searched queries or -1)."""
         sp = C.c_int32(0); rate = C.c_double(-1.0)
@@ -523,6 +550,23 @@ def estimate_motion_stereo(ego: EgoParams, match_lists, rand3, device: int = 0):
     inl = np.zeros(max(int(offsets[-1]), 1), np.int32)
     _check(_lib().vh_estimate_motion_stereo(C.byref(ego), device, n, _ptr(pm), _ptr(offsets), _ptr(rand3), _ptr(tr), _ptr(ok),
                                             _ptr(ninl), _ptr(inl)), "vh_estimate_motion_stereo")
+    return tr, ok.astype(bool), [inl[offsets[s]:offsets[s] + ninl[s]].copy() for s in range(n)]
+
+
+def estimate_motion_mono(mono: MonoParams, match_lists, rand8, device: int = 0):
+    """VisualOdometryMono::estimateMotion (reference src/viso_mono.cpp:41-160), batched over `match_lists`;
+    rand8 [n_sets, ransac_iters, 8] int32 rand() values.  -> (tr [n,6], ok [n] bool, [inlier index arrays])."""
+    lists = [np.ascontiguousarray(m, dtype=P_MATCH_DTYPE) for m in match_lists]
+    n = len(lists)
+    offsets = np.zeros(n + 1, np.int32)
+    offsets[1:] = np.cumsum([len(m) for m in lists])
+    pm = np.concatenate(lists) if offsets[-1] else np.zeros(0, P_MATCH_DTYPE)
+    rand8 = np.ascontiguousarray(rand8, np.int32)
+    assert rand8.shape == (n, mono.ransac_iters, 8)
+    tr = np.zeros((n, 6), np.float64); ok = np.zeros(n, np.int32); ninl = np.zeros(n, np.int32)
+    inl = np.zeros(max(int(offsets[-1]), 1), np.int32)
+    _check(_lib().vh_estimate_motion_mono(C.byref(mono), device, n, _ptr(pm), _ptr(offsets), _ptr(rand8), _ptr(tr), _ptr(ok),
+                                          _ptr(ninl), _ptr(inl)), "vh_estimate_motion_mono")
     return tr, ok.astype(bool), [inl[offsets[s]:offsets[s] + ninl[s]].copy() for s in range(n)]
 
 

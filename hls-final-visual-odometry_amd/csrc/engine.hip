@@ -189,6 +189,7 @@ struct Group {
     stats_pending[0] = stats_pending[1] = false;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
     d_ego_rand = nullptr; d_ego_ok = nullptr; d_ego_xyz = nullptr; d_ego_tr = nullptr; ego_rand_n = 0;
+    d_mono_scratch = nullptr; d_mono_rand = nullptr; mono_rand_n = 0;
     if (h_overflow) { (void)hipHostFree(h_overflow); h_overflow = nullptr; }
     allocated = false;
   }
@@ -727,8 +728,10 @@ struct Group {
     int32_t rc;
     if (!d_ego_xyz) {
       if ((rc = dmalloc(&d_ego_xyz, (size_t)S * mcap * 4, false))) return rc;
-      if ((rc = dmalloc(&d_ego_tr, 6 * (size_t)S, false))) return rc;
-      if ((rc = dmalloc(&d_ego_ok, 2 * (size_t)S, false))) return rc;
+      if (!d_ego_tr) {
+        if ((rc = dmalloc(&d_ego_tr, 6 * (size_t)S, false))) return rc;
+        if ((rc = dmalloc(&d_ego_ok, 2 * (size_t)S, false))) return rc;
+      }
     }
     if (ego_rand_n < nr) {  // (the old block stays in `allocs` until the group is released: a few KB per change of ransac_iters)
       if ((rc = dmalloc(&d_ego_rand, nr, false))) return rc;
@@ -742,6 +745,41 @@ struct Group {
     VH_HIP(hipMemcpyAsync(ok, d_ego_ok, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipMemcpyAsync(ninl, d_ego_ok + S, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
     // a truncated match list or feature set yields a pose of the truncated data: say so, as every get_matches path does
+    std::vector<int32_t> cnt((size_t)S);
+    VH_HIP(hipMemcpyAsync(cnt.data(), d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipStreamSynchronize(post_stream));
+    for (int32_t s = 0; s < S; s++) if (cnt[s] > mcap || h_overflow[s]) return VH_ERR_CAPACITY;
+    return VH_OK;
+  }
+
+  // VisualOdometryMono::estimateMotion on the device-resident match lists of every stream
+  uint8_t *d_mono_scratch = nullptr;
+  int32_t *d_mono_rand = nullptr;
+  size_t mono_rand_n = 0;
+  int32_t estimate_motion_mono(const vh_mono_params *e, const int32_t *rand8, double *tr, int32_t *ok, int32_t *ninl) {
+    if (!e || !rand8 || !tr || !ok || !ninl || e->ransac_iters < 1) return VH_ERR_INVALID_ARG;
+    if (!allocated || (last_method != VH_METHOD_FLOW && last_method != VH_METHOD_QUAD)) return VH_ERR_STATE;
+    const size_t nr = (size_t)S * e->ransac_iters * 8;
+    int32_t rc;
+    if (!d_mono_scratch) {
+      if ((rc = dmalloc(&d_mono_scratch, (size_t)vh_mono_scratch_bytes(S, mcap), false))) return rc;
+      if (!d_ego_tr) {
+        if ((rc = dmalloc(&d_ego_tr, 6 * (size_t)S, false))) return rc;
+        if ((rc = dmalloc(&d_ego_ok, 2 * (size_t)S, false))) return rc;
+      }
+    }
+    if (mono_rand_n < nr) {
+      if ((rc = dmalloc(&d_mono_rand, nr, false))) return rc;
+      mono_rand_n = nr;
+    }
+    VH_HIP(hipMemcpyAsync(d_mono_rand, rand8, sizeof(int32_t) * nr, hipMemcpyHostToDevice, post_stream));
+    vh_launch_mono(*e, S, (const vh_p_match *)d_matches, mcap, nullptr, d_match_count, mcap, d_mono_rand, d_mono_scratch, mcap, d_ego_tr,
+                   d_ego_ok, d_ego_ok + S, nullptr, 0, post_stream);
+    VH_HIP(hipGetLastError());
+    VH_HIP(hipMemcpyAsync(tr, d_ego_tr, sizeof(double) * 6 * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(ok, d_ego_ok, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
+    VH_HIP(hipMemcpyAsync(ninl, d_ego_ok + S, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
     std::vector<int32_t> cnt((size_t)S);
     VH_HIP(hipMemcpyAsync(cnt.data(), d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
     VH_HIP(hipMemcpyAsync(h_overflow, d_overflow, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, post_stream));
@@ -1159,6 +1197,59 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
     vh_launch_ego(*e, n_sets, (const vh_p_match *)d, 0, (const int32_t *)(d + o_off), nullptr, 0, (const int32_t *)(d + o_r),
                   (double *)(d + o_xyz), std::max<int64_t>(nmax, 1), (double *)(d + o_tr), (int32_t *)(d + o_ok), (int32_t *)(d + o_ok) + n_sets,
                   (int32_t *)(d + o_inl), 0, nullptr);
+    er = hipDeviceSynchronize();
+  }
+  if (er == hipSuccess) er = hipMemcpy(tr, d + o_tr, b_tr, hipMemcpyDeviceToHost);
+  if (er == hipSuccess) er = hipMemcpy(ok, d + o_ok, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
+  if (er == hipSuccess) er = hipMemcpy(n_inliers, d + o_ok + sizeof(int32_t) * (size_t)n_sets, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
+  if (er == hipSuccess && inliers && total) er = hipMemcpy(inliers, d + o_inl, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (er != hipSuccess) { t_last_error = hipGetErrorString(er); return VH_ERR_HIP; }
+  return VH_OK;
+}
+
+// ---- monocular egomotion -----------------------------------------
+void vh_default_mono_params(vh_mono_params *e) {
+  if (!e) return;
+  memset(e, 0, sizeof(*e));
+  e->ransac_iters = 2000; e->inlier_threshold = 0.00001; e->motion_threshold = 100.0;  // src/viso_mono.h:39-45
+  e->height = 1.0; e->pitch = 0.0; e->f = 1; e->cu = 0; e->cv = 0;                      // src/viso.h:46-48
+}
+int32_t vh_group_estimate_motion_mono(vh_group *g, const vh_mono_params *e, const int32_t *rand8, double *tr, int32_t *ok,
+                                      int32_t *n_inliers) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->estimate_motion_mono(e, rand8, tr, ok, n_inliers);
+}
+int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t n_sets, const vh_p_match *pm,
+                                const int32_t *offsets, const int32_t *rand8, double *tr, int32_t *ok, int32_t *n_inliers,
+                                int32_t *inliers) {
+  if (!e || n_sets < 1 || !offsets || !rand8 || !tr || !ok || !n_inliers || e->ransac_iters < 1) return VH_ERR_INVALID_ARG;
+  if (offsets[0] < 0) return VH_ERR_INVALID_ARG;
+  int64_t nmax = 0;
+  for (int32_t s = 0; s < n_sets; s++) {
+    if (offsets[s + 1] < offsets[s]) return VH_ERR_INVALID_ARG;
+    nmax = std::max<int64_t>(nmax, offsets[s + 1] - offsets[s]);
+  }
+  const int64_t total = offsets[n_sets], cap = std::max<int64_t>(nmax, 1);
+  if (total > 0 && !pm) return VH_ERR_INVALID_ARG;
+  const int32_t rc = select_device(device);
+  if (rc) return rc;
+  const size_t nr = (size_t)n_sets * e->ransac_iters * 8;
+  uint8_t *d = nullptr;
+  // one allocation: matches | offsets | rand8 | ok,ninl | inliers | tr | per-list scratch
+  const size_t b_pm = sizeof(vh_p_match) * (size_t)std::max<int64_t>(total, 1), b_off = sizeof(int32_t) * ((size_t)n_sets + 1);
+  const size_t b_r = sizeof(int32_t) * nr, b_ok = sizeof(int32_t) * 2 * (size_t)n_sets, b_inl = sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1);
+  const size_t b_tr = sizeof(double) * 6 * (size_t)n_sets, b_scr = (size_t)vh_mono_scratch_bytes(n_sets, cap);
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t o_off = up(b_pm), o_r = o_off + up(b_off), o_ok = o_r + up(b_r), o_inl = o_ok + up(b_ok), o_tr = o_inl + up(b_inl), o_scr = o_tr + up(b_tr);
+  VH_HIP(hipMalloc((void **)&d, o_scr + b_scr));
+  hipError_t er = hipSuccess;
+  if (total) er = hipMemcpy(d, pm, sizeof(vh_p_match) * (size_t)total, hipMemcpyHostToDevice);
+  if (er == hipSuccess) er = hipMemcpy(d + o_off, offsets, b_off, hipMemcpyHostToDevice);
+  if (er == hipSuccess) er = hipMemcpy(d + o_r, rand8, b_r, hipMemcpyHostToDevice);
+  if (er == hipSuccess) {
+    vh_launch_mono(*e, n_sets, (const vh_p_match *)d, 0, (const int32_t *)(d + o_off), nullptr, 0, (const int32_t *)(d + o_r), d + o_scr, cap,
+                   (double *)(d + o_tr), (int32_t *)(d + o_ok), (int32_t *)(d + o_ok) + n_sets, (int32_t *)(d + o_inl), 0, nullptr);
     er = hipDeviceSynchronize();
   }
   if (er == hipSuccess) er = hipMemcpy(tr, d + o_tr, b_tr, hipMemcpyDeviceToHost);

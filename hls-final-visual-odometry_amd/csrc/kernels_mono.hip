@@ -1,0 +1,835 @@
+// kernels_mono.hip -- batched monocular egomotion (8-point RANSAC + SVD) on gfx950, SURVEY 8(f-4).
+//
+// Replaces, for every camera stream of a batch:
+//   VisualOdometryMono::estimateMotion          (reference src/viso_mono.cpp:41-160)
+//   ...::normalizeFeaturePoints / fundamentalMatrix / getInlier / EtoRt / triangulateChieral /
+//        smallerThanMedian                      (src/viso_mono.cpp:162-399)
+//   Matrix::svd, operator*, lu/det              (src/matrix.cpp:579-802, :263-277, :400-415, :514-572)
+//   VisualOdometry::getRandomSample(N,8)        (src/viso.cpp:86-106), from caller-supplied rand() values
+//
+// Double precision (single where the reference's p_match fields are float), built with
+// -ffp-contract=off, every sum in the reference's order, so that each hypothesis' F -- and with it
+// every inlier set -- is bit-identical to the reference's; only exp/sin/cos/asin come from the device
+// library (the ground-plane vote and the final angles agree to rounding).
+//
+// Three launches per batch (S lists):
+//   mono_norm   one workgroup per list: centroids and scales (sequential sums, one lane each -- the
+//               order of a floating-point sum is part of the result), normalised points as float4.
+//   mono_hyp    one THREAD per RANSAC hypothesis, grid (iters/128, S): 8-point system, Matrix::svd of
+//               the 8x9 and of the 3x3 matrix in private memory, rank-2 F, Sampson inlier count over
+//               all matches; arg max per list with one 64-bit atomicMax (count << 32 | 2^31-1-k: more
+//               inliers win, the earlier hypothesis on ties, as the reference's strict `>`).
+//   mono_final  one workgroup per list: ordered inlier list of the winner, F from all inliers (a
+//               workgroup-cooperative Matrix::svd of the N x 9 system: independent columns / rows on
+//               different lanes, every sum sequential), E, the four (R,t) candidates, triangulation of
+//               every match (one 4x4 SVD per lane), chirality vote, median distance, ground-plane
+//               vote, angles.
+#include "vh_dev.h"
+#include "../../include/viso_hip.h"
+#include <math.h>
+
+namespace {
+
+#define MONO_T 256
+
+__device__ __forceinline__ double sign_of(double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); }
+
+__device__ double pythag(double a, double b) {  // src/matrix.cpp:846-854
+  const double absa = fabs(a), absb = fabs(b);
+  if (absa > absb) { const double q = absb / absa; return absa * sqrt(1.0 + (q == 0.0 ? 0.0 : q * q)); }
+  if (absb == 0.0) return 0.0;
+  const double q = absa / absb;
+  return absb * sqrt(1.0 + (q == 0.0 ? 0.0 : q * q));
+}
+
+// The diagonalisation of the bidiagonal form (src/matrix.cpp:669-761) as a sequence of plane
+// rotations: the scalars (w, rv1) are advanced here, each rotation of two columns of U or V is handed
+// to `rot_u(col_a, col_b, c, s)` / `rot_v(...)`, a negated column of V to `neg_v(col)`.  The scalars
+// never depend on U or V, so callers may apply the rotations to any partition of the rows.
+template <class RotU, class RotV, class NegV>
+__device__ __forceinline__ void svd_qr_phase(int n, double *w, double *rv1, double anorm, RotU rot_u, RotV rot_v, NegV neg_v) {
+  for (int k = n - 1; k >= 0; k--) {
+    for (int its = 0; its < 30; its++) {
+      int flag = 1, l, nm = 0;
+      for (l = k; l >= 0; l--) {
+        nm = l - 1;
+        if ((double)(fabs(rv1[l]) + anorm) == anorm) { flag = 0; break; }
+        if ((double)(fabs(w[nm]) + anorm) == anorm) break;
+      }
+      double c, s, f, g, h, x, y, z;
+      if (flag) {
+        c = 0.0; s = 1.0;
+        for (int i = l; i <= k; i++) {
+          f = s * rv1[i];
+          rv1[i] = c * rv1[i];
+          if ((double)(fabs(f) + anorm) == anorm) break;
+          g = w[i];
+          h = pythag(f, g);
+          w[i] = h;
+          h = 1.0 / h;
+          c = g * h;
+          s = -f * h;
+          rot_u(nm, i, c, s);
+        }
+      }
+      z = w[k];
+      if (l == k) {
+        if (z < 0.0) { w[k] = -z; neg_v(k); }
+        break;
+      }
+      x = w[l];
+      nm = k - 1;
+      y = w[nm];
+      g = rv1[nm];
+      h = rv1[k];
+      f = ((y - z) * (y + z) + (g - h) * (g + h)) / (2.0 * h * y);
+      g = pythag(f, 1.0);
+      f = ((x - z) * (x + z) + h * ((y / (f + sign_of(g, f))) - h)) / x;
+      c = s = 1.0;
+      for (int j = l; j <= nm; j++) {
+        const int i = j + 1;
+        g = rv1[i];
+        y = w[i];
+        h = s * g;
+        g = c * g;
+        z = pythag(f, h);
+        rv1[j] = z;
+        c = f / z;
+        s = h / z;
+        f = x * c + g * s;
+        g = g * c - x * s;
+        h = y * s;
+        y *= c;
+        rot_v(j, i, c, s);
+        z = pythag(f, h);
+        w[j] = z;
+        if (z) { z = 1.0 / z; c = f * z; s = h * z; }
+        f = c * g + s * y;
+        x = c * y - s * g;
+        rot_u(j, i, c, s);
+      }
+      rv1[l] = 0.0;
+      rv1[k] = f;
+      w[k] = x;
+    }
+  }
+}
+
+// The shell sort of the singular values (src/matrix.cpp:770-790) as a sequence of column moves:
+// save(col) -> temporary, move(dst, src), restore(dst) <- temporary.
+template <class Save, class Move, class Restore>
+__device__ __forceinline__ void svd_sort_phase(int n, double *w, Save save, Move move, Restore restore) {
+  int inc = 1;
+  do { inc *= 3; inc++; } while (inc <= n);
+  do {
+    inc /= 3;
+    for (int i = inc; i < n; i++) {
+      const double sw = w[i];
+      save(i);
+      int j = i;
+      while (w[j - inc] < sw) {
+        w[j] = w[j - inc];
+        move(j, j - inc);
+        j -= inc;
+        if (j < inc) break;
+      }
+      w[j] = sw;
+      restore(j);
+    }
+  } while (inc > 1);
+}
+
+// Matrix::svd (src/matrix.cpp:579-802) of a small m x n matrix held by ONE lane: a (row-major) is
+// replaced by the m x n factor U, w[n], v n x n; sorted, signs flipped.  tmp: n + max(m, n) + n doubles.
+__device__ void svd_lane(double *a, int m, int n, double *w, double *v, double *tmp) {
+  double *rv1 = tmp, *su = tmp + n, *sv = su + (m > n ? m : n);
+  int i, j, k, l = 0;
+  double anorm, f, g, h, s, scale;
+#define A(r, q) a[(r) * n + (q)]
+#define V(r, q) v[(r) * n + (q)]
+  for (i = 0; i < n * n; i++) v[i] = 0.0;
+  g = scale = anorm = 0.0;
+  for (i = 0; i < n; i++) {
+    l = i + 1;
+    rv1[i] = scale * g;
+    g = s = scale = 0.0;
+    if (i < m) {
+      for (k = i; k < m; k++) scale += fabs(A(k, i));
+      if (scale) {
+        for (k = i; k < m; k++) { A(k, i) /= scale; s += A(k, i) * A(k, i); }
+        f = A(i, i);
+        g = -sign_of(sqrt(s), f);
+        h = f * g - s;
+        A(i, i) = f - g;
+        for (j = l; j < n; j++) {
+          for (s = 0.0, k = i; k < m; k++) s += A(k, i) * A(k, j);
+          f = s / h;
+          for (k = i; k < m; k++) A(k, j) += f * A(k, i);
+        }
+        for (k = i; k < m; k++) A(k, i) *= scale;
+      }
+    }
+    w[i] = scale * g;
+    g = s = scale = 0.0;
+    if (i < m && i != n - 1) {
+      for (k = l; k < n; k++) scale += fabs(A(i, k));
+      if (scale) {
+        for (k = l; k < n; k++) { A(i, k) /= scale; s += A(i, k) * A(i, k); }
+        f = A(i, l);
+        g = -sign_of(sqrt(s), f);
+        h = f * g - s;
+        A(i, l) = f - g;
+        for (k = l; k < n; k++) rv1[k] = A(i, k) / h;
+        for (j = l; j < m; j++) {
+          for (s = 0.0, k = l; k < n; k++) s += A(j, k) * A(i, k);
+          for (k = l; k < n; k++) A(j, k) += s * rv1[k];
+        }
+        for (k = l; k < n; k++) A(i, k) *= scale;
+      }
+    }
+    const double t = fabs(w[i]) + fabs(rv1[i]);
+    anorm = anorm > t ? anorm : t;
+  }
+  for (i = n - 1; i >= 0; i--) {
+    if (i < n - 1) {
+      if (g) {
+        for (j = l; j < n; j++) V(j, i) = (A(i, j) / A(i, l)) / g;
+        for (j = l; j < n; j++) {
+          for (s = 0.0, k = l; k < n; k++) s += A(i, k) * V(k, j);
+          for (k = l; k < n; k++) V(k, j) += s * V(k, i);
+        }
+      }
+      for (j = l; j < n; j++) V(i, j) = V(j, i) = 0.0;
+    }
+    V(i, i) = 1.0;
+    g = rv1[i];
+    l = i;
+  }
+  for (i = (m < n ? m : n) - 1; i >= 0; i--) {
+    l = i + 1;
+    g = w[i];
+    for (j = l; j < n; j++) A(i, j) = 0.0;
+    if (g) {
+      g = 1.0 / g;
+      for (j = l; j < n; j++) {
+        for (s = 0.0, k = l; k < m; k++) s += A(k, i) * A(k, j);
+        f = (s / A(i, i)) * g;
+        for (k = i; k < m; k++) A(k, j) += f * A(k, i);
+      }
+      for (j = i; j < m; j++) A(j, i) *= g;
+    } else
+      for (j = i; j < m; j++) A(j, i) = 0.0;
+    ++A(i, i);
+  }
+  svd_qr_phase(n, w, rv1, anorm,
+    [&](int ca, int cb, double c, double s_) {
+      for (int r = 0; r < m; r++) { const double y = A(r, ca), z = A(r, cb); A(r, ca) = y * c + z * s_; A(r, cb) = z * c - y * s_; }
+    },
+    [&](int ca, int cb, double c, double s_) {
+      for (int r = 0; r < n; r++) { const double x = V(r, ca), z = V(r, cb); V(r, ca) = x * c + z * s_; V(r, cb) = z * c - x * s_; }
+    },
+    [&](int col) { for (int r = 0; r < n; r++) V(r, col) = -V(r, col); });
+  svd_sort_phase(n, w,
+    [&](int col) { for (int r = 0; r < m; r++) su[r] = A(r, col); for (int r = 0; r < n; r++) sv[r] = V(r, col); },
+    [&](int dst, int src) { for (int r = 0; r < m; r++) A(r, dst) = A(r, src); for (int r = 0; r < n; r++) V(r, dst) = V(r, src); },
+    [&](int col) { for (int r = 0; r < m; r++) A(r, col) = su[r]; for (int r = 0; r < n; r++) V(r, col) = sv[r]; });
+  for (k = 0; k < n; k++) {  // flip signs
+    int s2 = 0;
+    for (i = 0; i < m; i++) if (A(i, k) < 0.0) s2++;
+    for (j = 0; j < n; j++) if (V(j, k) < 0.0) s2++;
+    if (s2 > (m + n) / 2) {
+      for (i = 0; i < m; i++) A(i, k) = -A(i, k);
+      for (j = 0; j < n; j++) V(j, k) = -V(j, k);
+    }
+  }
+#undef A
+#undef V
+}
+
+// C = A (ma x na) * B (na x nb): Matrix::operator* (src/matrix.cpp:263-277), sums from 0, k ascending
+__device__ void matmul(const double *A, int ma, int na, const double *B, int nb, double *C) {
+  for (int i = 0; i < ma; i++)
+    for (int j = 0; j < nb; j++) {
+      double c = 0.0;
+      for (int k = 0; k < na; k++) c += A[i * na + k] * B[k * nb + j];
+      C[i * nb + j] = c;
+    }
+}
+__device__ void transpose3(const double *A, double *T) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[j * 3 + i] = A[i * 3 + j];
+}
+// Matrix::svd of a 3x3 followed by U * diag(W with W[2] = 0) * ~V (src/viso_mono.cpp:262-265, :91-94)
+__device__ void rank2_3x3(const double *M, double *out) {
+  double a[9], w[3], v[9], tmp[9], D[9], UD[9], Vt[9];
+  for (int i = 0; i < 9; i++) { a[i] = M[i]; D[i] = 0.0; }
+  svd_lane(a, 3, 3, w, v, tmp);
+  D[0] = w[0]; D[4] = w[1]; D[8] = 0.0;
+  matmul(a, 3, 3, D, 3, UD);
+  transpose3(v, Vt);
+  matmul(UD, 3, 3, Vt, 3, out);
+}
+
+// Matrix::det of a 3x3 (src/matrix.cpp:400-415) over Matrix::lu (:514-572)
+__device__ double det3(const double *M) {
+  double a[3][3], vv[3], big, dum, sum, temp, d = 1.0;
+  int imax = 0;
+  bool ok = true;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = M[i * 3 + j];
+  for (int i = 0; i < 3 && ok; i++) {
+    big = 0.0;
+    for (int j = 0; j < 3; j++) if ((temp = fabs(a[i][j])) > big) big = temp;
+    if (big == 0.0) { ok = false; break; }
+    vv[i] = 1.0 / big;
+  }
+  if (ok)
+    for (int j = 0; j < 3; j++) {
+      for (int i = 0; i < j; i++) {
+        sum = a[i][j];
+        for (int k = 0; k < i; k++) sum -= a[i][k] * a[k][j];
+        a[i][j] = sum;
+      }
+      big = 0.0;
+      for (int i = j; i < 3; i++) {
+        sum = a[i][j];
+        for (int k = 0; k < j; k++) sum -= a[i][k] * a[k][j];
+        a[i][j] = sum;
+        if ((dum = vv[i] * fabs(sum)) >= big) { big = dum; imax = i; }
+      }
+      if (j != imax) {
+        for (int k = 0; k < 3; k++) { dum = a[imax][k]; a[imax][k] = a[j][k]; a[j][k] = dum; }
+        d = -d;
+        vv[imax] = vv[j];
+      }
+      if (j != 2) {
+        dum = 1.0 / a[j][j];
+        for (int i = j + 1; i < 3; i++) a[i][j] *= dum;
+      }
+    }
+  for (int i = 0; i < 3; i++) d *= a[i][i];
+  return d;
+}
+
+struct MonoList {
+  const vh_p_match *pm;  // the list's matches
+  int32_t n;
+  float4 *pn;            // normalised (u1p, v1p, u1c, v1c)
+  double *A;             // [cap][9] refit system / its U factor
+  double *X;             // [4 solutions][4][cap] triangulated points
+  double *d, *dist;      // [cap] ground-plane coordinate / L1 distance of the points in front
+  int32_t *idx;          // [cap] inlier indices of the winner
+  double *hdr;           // [32] per list: Tp[9], Tc[9], status
+  unsigned long long *key;
+};
+
+// bytes of scratch per list: pn 16*cap | A 72*cap | X 128*cap | d 8*cap | dist 8*cap | idx 4*cap | hdr 256 | key 8, rounded to 16
+__host__ __device__ inline int64_t mono_per_list(int64_t cap) { return (236 * cap + 256 + 8 + 15) / 16 * 16; }
+
+__device__ __forceinline__ MonoList mono_list(int32_t s, const vh_p_match *pm_base, int64_t pm_stride, const int32_t *offsets,
+                                              const int32_t *counts, int32_t count_cap, uint8_t *scratch, int64_t cap) {
+  MonoList L;
+  L.pm = offsets ? pm_base + offsets[s] : pm_base + (int64_t)s * pm_stride;
+  L.n = offsets ? offsets[s + 1] - offsets[s] : min(counts[s], count_cap);
+  uint8_t *b = scratch + (int64_t)s * mono_per_list(cap);
+  L.pn = (float4 *)b; b += 16 * cap;
+  L.A = (double *)b; b += 72 * cap;
+  L.X = (double *)b; b += 128 * cap;
+  L.d = (double *)b; b += 8 * cap;
+  L.dist = (double *)b; b += 8 * cap;
+  L.hdr = (double *)b; b += 256;
+  L.key = (unsigned long long *)b; b += 8;
+  L.idx = (int32_t *)b;
+  return L;
+}
+
+// ------------------------------------------------------------------ mono_norm
+// normalizeFeaturePoints (src/viso_mono.cpp:187-233).  hdr[18] = 1: usable, 0: the reference returns
+// an empty vector (N < 10 or a degenerate scale).
+__global__ void __launch_bounds__(MONO_T)
+mono_norm_kernel(const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
+                 const int32_t *__restrict__ counts, int32_t count_cap, uint8_t *__restrict__ scratch, int64_t cap) {
+  __shared__ double sC[4], sS[2];
+  const int32_t s = blockIdx.x, tid = threadIdx.x;
+  const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
+  const int32_t N = L.n;
+  if (tid == 0) { *L.key = 0ull; L.hdr[18] = 0.0; }
+  if (N < 10) return;  // src/viso_mono.cpp:45-46
+  if (tid < 4) {       // centroids: one sequential sum per lane
+    double c = 0;
+    for (int32_t i = 0; i < N; i++) {
+      const vh_p_match &m = L.pm[i];
+      c += (double)(tid == 0 ? m.u1p : tid == 1 ? m.v1p : tid == 2 ? m.u1c : m.v1c);
+    }
+    sC[tid] = c / (double)N;
+  }
+  __syncthreads();
+  const double cpu = sC[0], cpv = sC[1], ccu = sC[2], ccv = sC[3];
+  float2 *fl = (float2 *)L.d;  // (scratch: the distances from the centroids)
+  for (int32_t i = tid; i < N; i += MONO_T) {
+    const vh_p_match &m = L.pm[i];
+    float4 q;
+    q.x = (float)((double)m.u1p - cpu); q.y = (float)((double)m.v1p - cpv);
+    q.z = (float)((double)m.u1c - ccu); q.w = (float)((double)m.v1c - ccv);
+    L.pn[i] = q;
+    fl[i] = make_float2(sqrtf(q.x * q.x + q.y * q.y), sqrtf(q.z * q.z + q.w * q.w));  // float expressions in the reference
+  }
+  __syncthreads();
+  if (tid < 2) {
+    double acc = 0;
+    for (int32_t i = 0; i < N; i++) acc += (double)(tid == 0 ? fl[i].x : fl[i].y);
+    sS[tid] = acc;
+  }
+  __syncthreads();
+  double sp = sS[0], sc = sS[1];
+  if (fabs(sp) < 1e-10 || fabs(sc) < 1e-10) return;
+  sp = sqrt(2.0) * (double)N / sp;
+  sc = sqrt(2.0) * (double)N / sc;
+  for (int32_t i = tid; i < N; i += MONO_T) {
+    float4 q = L.pn[i];
+    q.x = (float)((double)q.x * sp); q.y = (float)((double)q.y * sp);
+    q.z = (float)((double)q.z * sc); q.w = (float)((double)q.w * sc);
+    L.pn[i] = q;
+  }
+  if (tid == 0) {
+    double *Tp = L.hdr, *Tc = L.hdr + 9;
+    Tp[0] = sp; Tp[1] = 0; Tp[2] = -sp * cpu; Tp[3] = 0; Tp[4] = sp; Tp[5] = -sp * cpv; Tp[6] = 0; Tp[7] = 0; Tp[8] = 1;
+    Tc[0] = sc; Tc[1] = 0; Tc[2] = -sc * ccu; Tc[3] = 0; Tc[4] = sc; Tc[5] = -sc * ccv; Tc[6] = 0; Tc[7] = 0; Tc[8] = 1;
+    L.hdr[18] = 1.0;
+  }
+}
+
+// fundamentalMatrix on the 8 sampled matches (src/viso_mono.cpp:235-266), one lane
+__device__ void fundamental8(const float4 *pn, const int32_t *act, double *F) {
+  double a[72], w[9], v[81], tmp[27], F0[9];
+  for (int32_t i = 0; i < 8; i++) {
+    const float4 q = pn[act[i]];  // (u1p, v1p, u1c, v1c)
+    double *r = a + 9 * i;
+    r[0] = (double)(q.z * q.x); r[1] = (double)(q.z * q.y); r[2] = (double)q.z;  // float products
+    r[3] = (double)(q.w * q.x); r[4] = (double)(q.w * q.y); r[5] = (double)q.w;
+    r[6] = (double)q.x; r[7] = (double)q.y; r[8] = 1.0;
+  }
+  svd_lane(a, 8, 9, w, v, tmp);
+  for (int32_t i = 0; i < 9; i++) F0[i] = v[i * 9 + 8];
+  rank2_3x3(F0, F);
+}
+
+// getRandomSample(N, 8) from eight rand() values (src/viso.cpp:96-102)
+__device__ void sample8(const int32_t *r, int32_t N, int32_t *act) {
+  int32_t taken[8], nt = 0;
+  for (int32_t k = 0; k < 8; k++) {
+    int32_t j = (int32_t)((uint32_t)(r[k] & 0x7FFFFFFF) % (uint32_t)(N - k));
+    for (int32_t q = 0; q < nt; q++) if (j >= taken[q]) j++;
+    act[k] = j;
+    int32_t q = nt;
+    for (; q > 0 && taken[q - 1] > j; q--) taken[q] = taken[q - 1];
+    taken[q] = j; nt++;
+  }
+}
+
+// Sampson distance test of getInlier (src/viso_mono.cpp:283-309)
+__device__ __forceinline__ bool sampson_inlier(const double *F, const float4 q, double thr) {
+  const double u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
+  const double Fx1u = F[0] * u1 + F[1] * v1 + F[2], Fx1v = F[3] * u1 + F[4] * v1 + F[5], Fx1w = F[6] * u1 + F[7] * v1 + F[8];
+  const double Ftx2u = F[0] * u2 + F[3] * v2 + F[6], Ftx2v = F[1] * u2 + F[4] * v2 + F[7];
+  const double x2tFx1 = u2 * Fx1u + v2 * Fx1v + Fx1w;
+  const double d = x2tFx1 * x2tFx1 / (Fx1u * Fx1u + Fx1v * Fx1v + Ftx2u * Ftx2u + Ftx2v * Ftx2v);
+  return fabs(d) < thr;
+}
+
+// ------------------------------------------------------------------- mono_hyp
+__global__ void __launch_bounds__(128)
+mono_hyp_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
+                const int32_t *__restrict__ counts, int32_t count_cap, const int32_t *__restrict__ rand8,
+                uint8_t *__restrict__ scratch, int64_t cap) {
+  const int32_t s = blockIdx.y, k = blockIdx.x * 128 + threadIdx.x;
+  const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
+  if (L.hdr[18] == 0.0 || k >= e.ransac_iters) return;
+  int32_t act[8];
+  sample8(rand8 + ((int64_t)s * e.ransac_iters + k) * 8, L.n, act);
+  double F[9];
+  fundamental8(L.pn, act, F);
+  int32_t cnt = 0;
+  for (int32_t i = 0; i < L.n; i++) cnt += sampson_inlier(F, L.pn[i], e.inlier_threshold) ? 1 : 0;
+  // more inliers win, the earlier hypothesis on ties (strict `>` in iteration order, src/viso_mono.cpp:74);
+  // a hypothesis without inliers never replaces the initial empty set
+  if (cnt > 0) atomicMax(L.key, ((unsigned long long)cnt << 32) | (unsigned long long)(0x7FFFFFFF - k));
+}
+
+// ----------------------------------------------------------------- mono_final
+// Workgroup-cooperative Matrix::svd of the tall system A[m][9] (m >= 9) -- every lane of the
+// workgroup calls it.  The sums over the m rows of a column are sequential chains (their order is
+// part of the result), so the parallelism is across what the algorithm leaves independent: the
+// columns j > i of a left Householder step, the rows of a right one, the rows of every plane
+// rotation and column move.  The scalars of the QR phase are advanced redundantly by every lane
+// (same arithmetic, same values), so that phase needs no exchange at all.
+// On return: A = U (sorted, signs flipped), sV[81] = V, and w[9] in every lane.
+__device__ void svd_tall9(double *A, int m, double *sV, double *sX, int *sNeg, double *w, double *col_tmp) {
+  const int n = 9, tid = threadIdx.x;
+  double rv1[9];
+  int i, j, k, l = 0;
+  double anorm, f, g, h, s, scale;
+#define AA(r, q) A[(int64_t)(r) * 9 + (q)]
+#define VV(r, q) sV[(r) * 9 + (q)]
+  g = scale = anorm = 0.0;
+  for (i = 0; i < n; i++) {
+    l = i + 1;
+    rv1[i] = scale * g;
+    g = s = scale = 0.0;
+    // left Householder step on column i (i < m always: m >= 9)
+    if (tid == 0) {
+      double sc = 0.0;
+      for (k = i; k < m; k++) sc += fabs(AA(k, i));
+      sX[0] = sc;
+      if (sc) {
+        double ss = 0.0;
+        for (k = i; k < m; k++) { AA(k, i) /= sc; ss += AA(k, i) * AA(k, i); }
+        const double ff = AA(i, i), gg = -sign_of(sqrt(ss), ff);
+        sX[1] = gg; sX[2] = ff * gg - ss;
+        AA(i, i) = ff - gg;
+      }
+    }
+    __syncthreads();
+    scale = sX[0];
+    if (scale) {
+      g = sX[1]; h = sX[2];
+      if (tid >= l && tid < n) {
+        j = tid;
+        for (s = 0.0, k = i; k < m; k++) s += AA(k, i) * AA(k, j);
+        f = s / h;
+        for (k = i; k < m; k++) AA(k, j) += f * AA(k, i);
+      }
+      __syncthreads();
+      for (k = i + tid; k < m; k += MONO_T) AA(k, i) *= scale;
+    }
+    __syncthreads();
+    w[i] = scale * g;
+    g = s = scale = 0.0;
+    if (i != n - 1) {  // right Householder step on row i
+      if (tid == 0) {
+        double sc = 0.0;
+        for (k = l; k < n; k++) sc += fabs(AA(i, k));
+        sX[0] = sc;
+        if (sc) {
+          double ss = 0.0;
+          for (k = l; k < n; k++) { AA(i, k) /= sc; ss += AA(i, k) * AA(i, k); }
+          const double ff = AA(i, l), gg = -sign_of(sqrt(ss), ff), hh = ff * gg - ss;
+          AA(i, l) = ff - gg;
+          sX[1] = gg;
+          for (k = l; k < n; k++) sX[4 + k] = AA(i, k) / hh;
+        }
+      }
+      __syncthreads();
+      scale = sX[0];
+      if (scale) {
+        g = sX[1];
+        for (k = l; k < n; k++) rv1[k] = sX[4 + k];
+        for (j = l + tid; j < m; j += MONO_T) {
+          for (s = 0.0, k = l; k < n; k++) s += AA(j, k) * AA(i, k);
+          for (k = l; k < n; k++) AA(j, k) += s * rv1[k];
+        }
+        __syncthreads();
+        if (tid == 0) for (k = l; k < n; k++) AA(i, k) *= scale;
+      }
+      __syncthreads();
+    }
+    const double t = fabs(w[i]) + fabs(rv1[i]);
+    anorm = anorm > t ? anorm : t;
+  }
+  // accumulation of right-hand transformations: 9 x 9, one lane
+  if (tid == 0) {
+    double gg = g;
+    int ll = l;
+    for (i = 0; i < 81; i++) sV[i] = 0.0;
+    for (i = n - 1; i >= 0; i--) {
+      if (i < n - 1) {
+        if (gg) {
+          for (j = ll; j < n; j++) VV(j, i) = (AA(i, j) / AA(i, ll)) / gg;
+          for (j = ll; j < n; j++) {
+            double ss = 0.0;
+            for (k = ll; k < n; k++) ss += AA(i, k) * VV(k, j);
+            for (k = ll; k < n; k++) VV(k, j) += ss * VV(k, i);
+          }
+        }
+        for (j = ll; j < n; j++) VV(i, j) = VV(j, i) = 0.0;
+      }
+      VV(i, i) = 1.0;
+      gg = rv1[i];
+      ll = i;
+    }
+  }
+  __syncthreads();
+  // accumulation of left-hand transformations
+  for (i = n - 1; i >= 0; i--) {
+    l = i + 1;
+    g = w[i];
+    if (tid == 0) for (j = l; j < n; j++) AA(i, j) = 0.0;
+    __syncthreads();
+    if (g) {
+      g = 1.0 / g;
+      if (tid >= l && tid < n) {
+        j = tid;
+        for (s = 0.0, k = l; k < m; k++) s += AA(k, i) * AA(k, j);
+        f = (s / AA(i, i)) * g;
+        for (k = i; k < m; k++) AA(k, j) += f * AA(k, i);
+      }
+      __syncthreads();
+      for (j = i + tid; j < m; j += MONO_T) AA(j, i) *= g;
+    } else {
+      for (j = i + tid; j < m; j += MONO_T) AA(j, i) = 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) ++AA(i, i);
+    __syncthreads();
+  }
+  // QR phase and sort: every lane advances the scalars; lane r rotates / moves rows r, r + T, .. of U, lanes 0..8 row r of V
+  svd_qr_phase(n, w, rv1, anorm,
+    [&](int ca, int cb, double c, double s_) {
+      for (int r = tid; r < m; r += MONO_T) { const double y = AA(r, ca), z = AA(r, cb); AA(r, ca) = y * c + z * s_; AA(r, cb) = z * c - y * s_; }
+    },
+    [&](int ca, int cb, double c, double s_) {
+      if (tid < n) { const double x = VV(tid, ca), z = VV(tid, cb); VV(tid, ca) = x * c + z * s_; VV(tid, cb) = z * c - x * s_; }
+    },
+    [&](int col) { if (tid < n) VV(tid, col) = -VV(tid, col); });
+  {
+    // (the sort's temporary column: col_tmp[m] in global memory for U -- a lane only touches its own rows -- a register for V)
+    double sv = 0.0;
+    svd_sort_phase(n, w,
+      [&](int col) { for (int r = tid; r < m; r += MONO_T) col_tmp[r] = AA(r, col); if (tid < n) sv = VV(tid, col); },
+      [&](int dst, int src) { for (int r = tid; r < m; r += MONO_T) AA(r, dst) = AA(r, src); if (tid < n) VV(tid, dst) = VV(tid, src); },
+      [&](int col) { for (int r = tid; r < m; r += MONO_T) AA(r, col) = col_tmp[r]; if (tid < n) VV(tid, col) = sv; });
+  }
+  // flip signs: count the negative elements of each (U column, V column)
+  if (tid < n) sNeg[tid] = 0;
+  __syncthreads();
+  for (k = 0; k < n; k++) {
+    int cnt = 0;
+    for (int r = tid; r < m; r += MONO_T) cnt += AA(r, k) < 0.0 ? 1 : 0;
+    if (tid < n) cnt += VV(tid, k) < 0.0 ? 1 : 0;
+    if (cnt) atomicAdd(&sNeg[k], cnt);
+  }
+  __syncthreads();
+  for (k = 0; k < n; k++)
+    if (sNeg[k] > (m + n) / 2) {
+      for (int r = tid; r < m; r += MONO_T) AA(r, k) = -AA(r, k);
+      if (tid < n) VV(tid, k) = -VV(tid, k);
+    }
+  __syncthreads();
+#undef AA
+#undef VV
+}
+
+__global__ void __launch_bounds__(MONO_T)
+mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
+                  const int32_t *__restrict__ counts, int32_t count_cap, const int32_t *__restrict__ rand8, uint8_t *__restrict__ scratch,
+                  int64_t cap, double *__restrict__ tr_out, int32_t *__restrict__ ok_out, int32_t *__restrict__ ninl_out,
+                  int32_t *__restrict__ inl_out, int64_t inl_stride) {
+  __shared__ double sF[9], sV[81], sX[16], sM[48];  // sM: R candidates Ra[9], Rb[9], t0[3], P1/P2 rows ...
+  __shared__ double sP[4][12];                      // P2 of the four (R, t) candidates
+  __shared__ double sK[12];                         // P1 = [K | 0]
+  __shared__ int32_t sNeg[9], sWave[MONO_T / 64], sBase, sCnt[4], sFlag;
+  const int32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
+  const int32_t N = L.n;
+  int32_t *inl = inl_out ? inl_out + (offsets ? (int64_t)offsets[s] : (int64_t)s * inl_stride) : nullptr;
+  auto fail = [&](int32_t ninl) {
+    if (tid == 0) { ok_out[s] = 0; ninl_out[s] = ninl; for (int32_t q = 0; q < 6; q++) tr_out[6 * s + q] = 0.0; }
+  };
+  if (L.hdr[18] == 0.0) { fail(0); return; }
+  const unsigned long long key = *L.key;
+  const int32_t nbest = (int32_t)(key >> 32);
+  if (nbest == 0) { fail(0); return; }
+  // the winner's F again (same code, same bits as in mono_hyp)
+  if (tid == 0) {
+    const int32_t kbest = 0x7FFFFFFF - (int32_t)(uint32_t)key;
+    int32_t act[8];
+    sample8(rand8 + ((int64_t)s * e.ransac_iters + kbest) * 8, N, act);
+    double F[9];
+    fundamental8(L.pn, act, F);
+    for (int32_t q = 0; q < 9; q++) sF[q] = F[q];
+    sBase = 0;
+  }
+  __syncthreads();
+  // its ordered inlier list (VisualOdometry::inliers)
+  {
+    double F[9];
+    for (int32_t q = 0; q < 9; q++) F[q] = sF[q];
+    for (int32_t i0 = 0; i0 < N; i0 += MONO_T) {
+      const int32_t i = i0 + tid;
+      const bool in_ = i < N && sampson_inlier(F, L.pn[min(i, N - 1)], e.inlier_threshold);
+      const uint64_t bal = __ballot(in_);
+      if (lane == 0) sWave[wv] = __popcll(bal);
+      __syncthreads();
+      int32_t off = sBase;
+      for (int32_t q = 0; q < wv; q++) off += sWave[q];
+      if (in_) {
+        const int32_t p = off + __popcll(bal & ((1ull << lane) - 1));
+        L.idx[p] = i;
+        if (inl) inl[p] = i;
+      }
+      __syncthreads();
+      if (tid == 0) sBase += sWave[0] + sWave[1] + sWave[2] + sWave[3];
+      __syncthreads();
+    }
+  }
+  if (nbest < 10) { fail(nbest); return; }  // src/viso_mono.cpp:80-81
+  // F from all inliers: the nbest x 9 system (src/viso_mono.cpp:84, :242-256)
+  for (int32_t i = tid; i < nbest; i += MONO_T) {
+    const float4 q = L.pn[L.idx[i]];
+    double *r = L.A + (int64_t)i * 9;
+    r[0] = (double)(q.z * q.x); r[1] = (double)(q.z * q.y); r[2] = (double)q.z;
+    r[3] = (double)(q.w * q.x); r[4] = (double)(q.w * q.y); r[5] = (double)q.w;
+    r[6] = (double)q.x; r[7] = (double)q.y; r[8] = 1.0;
+  }
+  __syncthreads();
+  double w9[9];
+  svd_tall9(L.A, nbest, sV, sX, sNeg, w9, L.d);
+  if (tid == 0) {
+    double F0[9], F[9], T1[9], T2[9], E[9], Kt[9];
+    const double K[9] = {e.f, 0, e.cu, 0, e.f, e.cv, 0, 0, 1};
+    for (int32_t q = 0; q < 9; q++) F0[q] = sV[q * 9 + 8];
+    rank2_3x3(F0, F);
+    // denormalise, essential matrix, rank 2 again (src/viso_mono.cpp:86-94)
+    transpose3(L.hdr + 9, T1); matmul(T1, 3, 3, F, 3, T2); matmul(T2, 3, 3, L.hdr, 3, F);
+    transpose3(K, Kt); matmul(Kt, 3, 3, F, 3, T2); matmul(T2, 3, 3, K, 3, E);
+    rank2_3x3(E, T1);
+    for (int32_t q = 0; q < 9; q++) E[q] = T1[q];
+    // EtoRt (src/viso_mono.cpp:317-346)
+    const double Wm[9] = {0, -1, 0, +1, 0, 0, 0, 0, 1}, Zm[9] = {0, +1, 0, -1, 0, 0, 0, 0, 0};
+    double U[9], S[3], V[9], tmp[9], Ut[9], Vt[9], Wt[9], T[9];
+    for (int32_t q = 0; q < 9; q++) U[q] = E[q];
+    svd_lane(U, 3, 3, S, V, tmp);
+    transpose3(U, Ut); transpose3(V, Vt); transpose3(Wm, Wt);
+    matmul(U, 3, 3, Zm, 3, T1); matmul(T1, 3, 3, Ut, 3, T);
+    double *Ra = sM, *Rb = sM + 9, *t0 = sM + 18;
+    matmul(U, 3, 3, Wm, 3, T1); matmul(T1, 3, 3, Vt, 3, Ra);
+    matmul(U, 3, 3, Wt, 3, T1); matmul(T1, 3, 3, Vt, 3, Rb);
+    t0[0] = T[2 * 3 + 1]; t0[1] = T[0 * 3 + 2]; t0[2] = T[1 * 3 + 0];
+    if (det3(Ra) < 0) for (int32_t q = 0; q < 9; q++) Ra[q] = -Ra[q];
+    if (det3(Rb) < 0) for (int32_t q = 0; q < 9; q++) Rb[q] = -Rb[q];
+    // projection matrices of triangulateChieral (src/viso_mono.cpp:370-375)
+    for (int32_t i = 0; i < 3; i++) for (int32_t j = 0; j < 4; j++) sK[i * 4 + j] = j < 3 ? K[i * 3 + j] : 0.0;
+    for (int32_t c = 0; c < 4; c++) {
+      const double *R = c < 2 ? Ra : Rb;
+      double Rt[12];
+      for (int32_t i = 0; i < 3; i++) { for (int32_t j = 0; j < 3; j++) Rt[i * 4 + j] = R[i * 3 + j]; Rt[i * 4 + 3] = (c & 1) ? -t0[i] : t0[i]; }
+      matmul(K, 3, 3, Rt, 4, sP[c]);
+    }
+    for (int32_t c = 0; c < 4; c++) sCnt[c] = 0;
+  }
+  __syncthreads();
+  // triangulation of every match under each candidate: one 4x4 Matrix::svd per lane (src/viso_mono.cpp:378-387)
+  for (int32_t c = 0; c < 4; c++) {
+    double *Xc = L.X + (int64_t)c * 4 * cap;
+    int32_t good = 0;
+    for (int32_t i = tid; i < N; i += MONO_T) {
+      const vh_p_match &m = L.pm[i];
+      double J[16], w4[4], V4[16], tmp[12];
+      for (int32_t j = 0; j < 4; j++) {
+        J[0 * 4 + j] = sK[2 * 4 + j] * m.u1p - sK[0 * 4 + j];
+        J[1 * 4 + j] = sK[2 * 4 + j] * m.v1p - sK[1 * 4 + j];
+        J[2 * 4 + j] = sP[c][2 * 4 + j] * m.u1c - sP[c][0 * 4 + j];
+        J[3 * 4 + j] = sP[c][2 * 4 + j] * m.v1c - sP[c][1 * 4 + j];
+      }
+      svd_lane(J, 4, 4, w4, V4, tmp);
+      double x[4], a = 0.0, b = 0.0;
+      for (int32_t j = 0; j < 4; j++) { x[j] = V4[j * 4 + 3]; Xc[(int64_t)j * cap + i] = x[j]; }
+      for (int32_t j = 0; j < 4; j++) a += sK[2 * 4 + j] * x[j];
+      for (int32_t j = 0; j < 4; j++) b += sP[c][2 * 4 + j] * x[j];
+      good += (a * x[3] > 0 && b * x[3] > 0) ? 1 : 0;
+    }
+    if (good) atomicAdd(&sCnt[c], good);
+  }
+  __syncthreads();
+  int32_t cbest = -1, max_in = 0;
+  for (int32_t c = 0; c < 4; c++) if (sCnt[c] > max_in) { max_in = sCnt[c]; cbest = c; }  // strict `>`, src/viso_mono.cpp:353
+  if (cbest < 0) { fail(nbest); return; }  // (the reference dereferences an empty matrix here)
+  // X / X(3,:), the points in front in match order, their L1 distance and ground-plane coordinate (src/viso_mono.cpp:100-128)
+  const double *Xb = L.X + (int64_t)cbest * 4 * cap;
+  const double n0 = cos(-e.pitch), n1 = sin(-e.pitch);
+  if (tid == 0) sBase = 0;
+  __syncthreads();
+  for (int32_t i0 = 0; i0 < N; i0 += MONO_T) {
+    const int32_t i = i0 + tid;
+    double x = 0, y = 0, z = 0;
+    if (i < N) {
+      const double wq = Xb[(int64_t)3 * cap + i];
+      if (wq != 0) { x = Xb[i] / wq; y = Xb[(int64_t)cap + i] / wq; z = Xb[(int64_t)2 * cap + i] / wq; }
+    }
+    const bool front = i < N && z > 0;
+    const uint64_t bal = __ballot(front);
+    if (lane == 0) sWave[wv] = __popcll(bal);
+    __syncthreads();
+    int32_t off = sBase;
+    for (int32_t q = 0; q < wv; q++) off += sWave[q];
+    if (front) {
+      const int32_t p = off + __popcll(bal & ((1ull << lane) - 1));
+      L.dist[p] = fabs(x) + fabs(y) + fabs(z);
+      double dd = 0.0;
+      dd += n0 * y; dd += n1 * z;
+      L.d[p] = dd;
+    }
+    __syncthreads();
+    if (tid == 0) sBase += sWave[0] + sWave[1] + sWave[2] + sWave[3];
+    __syncthreads();
+  }
+  const int32_t np = sBase;
+  if (np < 10) { fail(nbest); return; }
+  // median = element number np/2 of the sorted distances (smallerThanMedian): its rank by counting
+  const int32_t half = np / 2;
+  for (int32_t i = tid; i < np; i += MONO_T) {
+    const double v = L.dist[i];
+    int32_t rank = 0;
+    for (int32_t j = 0; j < np; j++) { const double o = L.dist[j]; rank += (o < v || (o == v && j < i)) ? 1 : 0; }
+    if (rank == half) sX[0] = v;
+  }
+  __syncthreads();
+  const double median = sX[0];
+  if (median > e.motion_threshold) { fail(nbest); return; }
+  const double sigma = median / 50.0, weight = 1.0 / (2.0 * sigma * sigma);
+  // ground-plane vote (src/viso_mono.cpp:130-148): each lane sums the kernel over all j in order for its
+  // candidates i (the sums replace the distances, which are dead); the first i with the largest sum wins
+  for (int32_t i = tid; i < np; i += MONO_T) {
+    double sum = 0;
+    if (L.d[i] > median / e.motion_threshold)
+      for (int32_t j = 0; j < np; j++) { const double q = L.d[j] - L.d[i]; sum += exp(-q * q * weight); }
+    L.dist[i] = sum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double best_sum = 0;
+    int32_t best_idx = 0;
+    for (int32_t i = 0; i < np; i++) if (L.dist[i] > best_sum) { best_sum = L.dist[i]; best_idx = i; }
+    const double dref = L.d[best_idx];
+    int32_t okf = 1;
+    if (fabs(dref) < 1e-20) okf = 0;  // (Matrix::operator/ exits the reference here)
+    if (okf) {
+      const double *R = cbest < 2 ? sM : sM + 9, *t0 = sM + 18;
+      double t[3];
+      for (int32_t q = 0; q < 3; q++) { const double tq = (cbest & 1) ? -t0[q] : t0[q]; t[q] = (tq * e.height) / dref; }
+      const double ry = asin(R[0 * 3 + 2]);
+      tr_out[6 * s + 0] = asin(-R[1 * 3 + 2] / cos(ry));
+      tr_out[6 * s + 1] = ry;
+      tr_out[6 * s + 2] = asin(-R[0 * 3 + 1] / cos(ry));
+      tr_out[6 * s + 3] = t[0]; tr_out[6 * s + 4] = t[1]; tr_out[6 * s + 5] = t[2];
+      ok_out[s] = 1; ninl_out[s] = nbest;
+    }
+    sFlag = okf;
+  }
+  __syncthreads();
+  if (!sFlag) fail(nbest);
+}
+
+}  // namespace
+
+int64_t vh_mono_scratch_bytes(int32_t n_sets, int64_t cap) {
+  return (int64_t)n_sets * mono_per_list(cap);
+}
+
+void vh_launch_mono(const vh_mono_params &e, int32_t n_sets, const vh_p_match *pm, int64_t pm_stride, const int32_t *offsets,
+                    const int32_t *counts, int32_t count_cap, const int32_t *rand8, uint8_t *scratch, int64_t cap, double *tr,
+                    int32_t *ok, int32_t *ninl, int32_t *inl, int64_t inl_stride, hipStream_t st) {
+  hipLaunchKernelGGL(mono_norm_kernel, dim3(n_sets), dim3(MONO_T), 0, st, pm, pm_stride, offsets, counts, count_cap, scratch, cap);
+  hipLaunchKernelGGL(mono_hyp_kernel, dim3((e.ransac_iters + 127) / 128, n_sets), dim3(128), 0, st, e, pm, pm_stride, offsets, counts,
+                     count_cap, rand8, scratch, cap);
+  hipLaunchKernelGGL(mono_final_kernel, dim3(n_sets), dim3(MONO_T), 0, st, e, pm, pm_stride, offsets, counts, count_cap, rand8, scratch,
+                     cap, tr, ok, ninl, inl, inl_stride);
+}

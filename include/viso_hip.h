@@ -313,6 +313,40 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
 int32_t vh_group_estimate_motion(vh_group *g, const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok,
                                  int32_t *n_inliers);
 
+/* ---- monocular egomotion (mono half) ---------------------------- */
+
+/* VisualOdometryMono::parameters and the calibration it reads (src/viso_mono.h:32-46, src/viso.h:41-50). */
+typedef struct vh_mono_params {
+  int32_t ransac_iters;     /* number of RANSAC iterations (2000) */
+  int32_t reserved_;        /* 0 */
+  double inlier_threshold;  /* fundamental-matrix (Sampson distance) inlier threshold (0.00001) */
+  double motion_threshold;  /* median depth above which the motion counts as too small (100.0) */
+  double height, pitch;     /* camera height above ground (m), pitch (rad, negative = pointing down) */
+  double f, cu, cv;         /* focal length and principal point (pixels) */
+} vh_mono_params;
+/* VisualOdometryMono::parameters() defaults; f = 1, cu = cv = 0 as VisualOdometry::calibration(). */
+void vh_default_mono_params(vh_mono_params *e);
+
+/* VisualOdometryMono::estimateMotion (src/viso_mono.cpp:41-160) for n_sets independent lists of flow
+ * matches (u1p,v1p -> u1c,v1c; the other fields are not read): 8-point RANSAC on normalised points,
+ * F from all inliers of the best hypothesis, E, the four (R,t) candidates with the chirality vote,
+ * scale from the ground plane.  Same layout as vh_estimate_motion_stereo; rand8[n_sets][ransac_iters][8]
+ * = the values rand() returns while getRandomSample(N,8) draws each hypothesis' sample
+ * (src/viso.cpp:86-106).  ok = 0 (tr = 0) where the reference returns an empty vector (fewer than
+ * 10 matches / inliers / points in front of the cameras, median depth above motion_threshold) --
+ * and where it would call exit(0) (no chirality solution, division by a vanishing plane distance).
+ * Every hypothesis, the refit and the triangulation follow the reference's operation order exactly
+ * (Matrix::svd restated, src/matrix.cpp:579-802), so the inlier sets are equal to the reference's;
+ * the ground-plane vote uses the device's exp and the angles its asin/cos, so tr agrees to rounding
+ * (tests assert 1e-9 relative). */
+int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t n_sets, const vh_p_match *pm,
+                                const int32_t *offsets, const int32_t *rand8, double *tr, int32_t *ok,
+                                int32_t *n_inliers, int32_t *inliers);
+/* The same on the device-resident match lists of the group's last vh_group_match_features
+ * (VH_METHOD_FLOW or VH_METHOD_QUAD: both carry the left camera's flow). */
+int32_t vh_group_estimate_motion_mono(vh_group *g, const vh_mono_params *e, const int32_t *rand8, double *tr,
+                                      int32_t *ok, int32_t *n_inliers);
+
 /* Which form of the search loops the group currently runs and the last observed share of
  * queries the speculative form had to search again (-1 before the first report).  The
  * searches are exact either way; the library switches between a speculative loop (no accept

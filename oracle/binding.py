@@ -54,6 +54,21 @@ class EgoParams(C.Structure):
         return e
 
 
+class MonoParams(C.Structure):
+    """VisualOdometryMono::parameters + calibration (reference src/viso_mono.h:32-46, src/viso.h:41-50)."""
+    _fields_ = [("ransac_iters", C.c_int32), ("pad_", C.c_int32), ("inlier_threshold", C.c_double), ("motion_threshold", C.c_double),
+                ("height", C.c_double), ("pitch", C.c_double), ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double)]
+
+    @classmethod
+    def default(cls, **kw):
+        e = cls(ransac_iters=2000, pad_=0, inlier_threshold=0.00001, motion_threshold=100.0, height=1.0, pitch=0.0, f=1.0, cu=0.0, cv=0.0)
+        for k, v in kw.items():
+            if not hasattr(e, k):
+                raise AttributeError(k)
+            setattr(e, k, v)
+        return e
+
+
 def glibc_rand_after_srand0(count: int) -> np.ndarray:
     """The first `count` values of rand() after srand(0): what the reference's
     VisualOdometry constructor seeds (src/viso.cpp:35) and getRandomSample consumes."""
@@ -237,6 +252,34 @@ class Oracle:
         return bool(ok), tr, inl[:n.value].copy()
 
 
+    # ---- monocular egomotion ----------------------------------------------
+    def draw_samples_n(self, n_matches: int, num: int, iters: int, rand_values=None) -> np.ndarray:
+        """VisualOdometry::getRandomSample(N,num) x iters (src/viso.cpp:86-106) -> [iters,num] int32."""
+        r = glibc_rand_after_srand0(num * iters) if rand_values is None else np.ascontiguousarray(rand_values, np.int32)
+        assert r.size >= num * iters
+        out = np.zeros((iters, num), np.int32)
+        self.lib.vo_draw_samples_n(C.c_int32(n_matches), C.c_int32(num), C.c_int32(iters), _ptr(r), _ptr(out))
+        return out
+
+    def svd(self, a):
+        """Matrix::svd (src/matrix.cpp:579-802) -> (U2 [m,m], W [min(m,n)], V [n,n])."""
+        a = np.ascontiguousarray(a, np.float64)
+        m, n = a.shape
+        U = np.zeros((m, m)); W = np.zeros(min(m, n)); V = np.zeros((n, n))
+        self.lib.vo_svd(_ptr(a), C.c_int32(m), C.c_int32(n), _ptr(U), _ptr(W), _ptr(V))
+        return U, W, V
+
+    def estimate_motion_mono(self, mono, pm, samples):
+        """VisualOdometryMono::estimateMotion (src/viso_mono.cpp:41-160) -> (ok, tr[6], inlier indices)."""
+        pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE)
+        samples = np.ascontiguousarray(samples, np.int32)
+        assert samples.shape == (mono.ransac_iters, 8)
+        tr = np.zeros(6, np.float64); inl = np.zeros(max(len(pm), 1), np.int32); n = C.c_int32(0)
+        self.lib.vo_estimate_motion_mono.restype = C.c_int32
+        ok = self.lib.vo_estimate_motion_mono(C.byref(mono), _ptr(pm), C.c_int32(len(pm)), _ptr(samples), _ptr(tr), _ptr(inl), C.byref(n))
+        return bool(ok), tr, inl[:n.value].copy()
+
+
 class Reference:
     """The reference's own CPU/SSE code (oracle/_ref/libviso_ref.so)."""
 
@@ -336,3 +379,19 @@ class Reference:
         self.lib.ref_estimate_motion_stereo.restype = C.c_int32
         ok = self.lib.ref_estimate_motion_stereo(C.byref(ego), _ptr(pm), C.c_int32(len(pm)), _ptr(tr), _ptr(inl), C.byref(n))
         return bool(ok), tr, inl[:n.value].copy()
+
+    def estimate_motion_mono(self, mono, pm):
+        """The reference's VisualOdometryMono::estimateMotion on a fresh object (srand(0))."""
+        pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE)
+        tr = np.zeros(6, np.float64); inl = np.zeros(max(len(pm), 1), np.int32); n = C.c_int32(0)
+        self.lib.ref_estimate_motion_mono.restype = C.c_int32
+        ok = self.lib.ref_estimate_motion_mono(C.byref(mono), _ptr(pm), C.c_int32(len(pm)), _ptr(tr), _ptr(inl), C.byref(n))
+        return bool(ok), tr, inl[:n.value].copy()
+
+    def svd(self, a):
+        """The reference's Matrix::svd."""
+        a = np.ascontiguousarray(a, np.float64)
+        m, n = a.shape
+        U = np.zeros((m, m)); W = np.zeros(min(m, n)); V = np.zeros((n, n))
+        self.lib.ref_svd(_ptr(a), C.c_int32(m), C.c_int32(n), _ptr(U), _ptr(W), _ptr(V))
+        return U, W, V

@@ -31,6 +31,7 @@
 #define private public
 #include "matcher.cpp"
 #include "viso_stereo.h"   /* estimateMotion is private (src/viso_stereo.h:75) */
+#include "viso_mono.h"     /* ... and src/viso_mono.h:74 */
 #undef private
 #include "filter.h"
 
@@ -257,6 +258,37 @@ int32_t ref_estimate_motion_stereo(const void *ego, const void *pm, int32_t n, d
   for (int i = 0; i < 6; i++) tr[i] = r.size() == 6 ? r[i] : 0.0;
   delete vo;
   return r.size() == 6 ? 1 : 0;
+}
+
+/* SURVEY 8(f-4), mono half: VisualOdometryMono::estimateMotion (src/viso_mono.cpp:41-160) on
+ * caller-supplied flow matches, with a freshly constructed object (srand(0) in the constructor, so
+ * the samples are getRandomSample(N,8) on rand()'s first 8*ransac_iters values).
+ * mono: {int32 ransac_iters, pad; double inlier_threshold, motion_threshold, height, pitch, f, cu, cv}. */
+struct HMono { int32_t ransac_iters, pad; double inlier_threshold, motion_threshold, height, pitch, f, cu, cv; };
+int32_t ref_estimate_motion_mono(const void *mono, const void *pm, int32_t n, double *tr, int32_t *inliers, int32_t *n_inliers) {
+  const HMono *e = (const HMono *)mono;
+  VisualOdometryMono::parameters param;
+  param.ransac_iters = e->ransac_iters; param.inlier_threshold = e->inlier_threshold; param.motion_threshold = e->motion_threshold;
+  param.height = e->height; param.pitch = e->pitch;
+  param.calib.f = e->f; param.calib.cu = e->cu; param.calib.cv = e->cv;
+  VisualOdometryMono *vo = new VisualOdometryMono(param);
+  std::vector<Matcher::p_match> v((const Matcher::p_match *)pm, (const Matcher::p_match *)pm + n);
+  std::vector<double> r = vo->estimateMotion(v);
+  std::vector<int32_t> inl = vo->getInlierIndices();
+  *n_inliers = (int32_t)inl.size();
+  for (size_t i = 0; i < inl.size(); i++) inliers[i] = inl[i];
+  for (int i = 0; i < 6; i++) tr[i] = r.size() == 6 ? r[i] : 0.0;
+  delete vo;
+  return r.size() == 6 ? 1 : 0;
+}
+
+/* Matrix::svd (src/matrix.cpp:579-802) on a row-major m x n array: U2 m x m, W min(m,n), V n x n. */
+void ref_svd(const double *a, int32_t m, int32_t n, double *U2, double *W, double *V) {
+  Matrix A(m, n, a), U, S, Vm;
+  A.svd(U, S, Vm);
+  for (int32_t i = 0; i < m; i++) for (int32_t j = 0; j < m; j++) U2[i * m + j] = U.val[i][j];
+  for (int32_t i = 0; i < S.m; i++) W[i] = S.val[i][0];
+  for (int32_t i = 0; i < n; i++) for (int32_t j = 0; j < n; j++) V[i * n + j] = Vm.val[i][j];
 }
 
 }  // extern "C"

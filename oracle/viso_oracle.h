@@ -163,6 +163,26 @@ void vo_draw_samples(int32_t N, int32_t iters, const int32_t *r, int32_t *sample
 int32_t vo_estimate_motion_stereo(const vo_ego_params *e, const vo_p_match *pm, int32_t n, const int32_t *samples,
                                   double tr[6], int32_t *inliers, int32_t *n_inliers);
 
+/* ---- monocular egomotion (viso_mono.c) ---------------------- */
+/* VisualOdometryMono::parameters (src/viso_mono.h:32-46) + the calibration it uses (src/viso.h:41-50). */
+typedef struct vo_mono_params {
+  int32_t ransac_iters;      /* 2000 */
+  int32_t pad_;
+  double inlier_threshold;   /* 0.00001 */
+  double motion_threshold;   /* 100.0 */
+  double height, pitch;      /* 1.0, 0.0 */
+  double f, cu, cv;
+} vo_mono_params;
+void vo_default_mono_params(vo_mono_params *e);
+/* [pinned] Matrix::svd (src/matrix.cpp:579-802) as its callers see it: a m x n row-major -> U2 m x m (may be NULL),
+ * W[min(m,n)], V n x n. */
+void vo_svd(const double *a, int32_t m, int32_t n, double *U2, double *W, double *V);
+/* [pinned] VisualOdometry::getRandomSample(N,num) x iters from successive rand() values r[num*iters]. */
+void vo_draw_samples_n(int32_t N, int32_t num, int32_t iters, const int32_t *r, int32_t *samples);
+/* [pinned] VisualOdometryMono::estimateMotion (src/viso_mono.cpp:41-160) with given 8-point samples [iters][8]. */
+int32_t vo_estimate_motion_mono(const vo_mono_params *e, const vo_p_match *pm, int32_t n, const int32_t *samples,
+                                double tr[6], int32_t *inliers, int32_t *n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,3 +39,36 @@ def scene(dtype, n, seed, tr=(0.004, -0.012, 0.002, 0.03, -0.01, -0.85), outlier
         r["i1p"] = r["i2p"] = r["i1c"] = r["i2c"] = k
         k += 1
     return out, np.array(tr)
+
+
+def mono_scene(dtype, n, seed, tr=(0.002, -0.01, 0.001, 0.02, -0.005, -0.9), outliers=0.2, ground=0.45, height=1.65, f=645.24, cu=635.96,
+               cv=194.13, W=1241, H=376, noise=0.0):
+    """Flow matches of ONE camera (right-camera fields = -1, as Matcher::matching method 0 emits them):
+    a share `ground` of the points lies on the road plane Y = height below the camera (the mono
+    estimator scales its translation by that plane), the rest is structure above it."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros(n, dtype)
+    for name in out.dtype.names:
+        out[name] = -1
+    R, t = rot(*tr[:3]), np.array(tr[3:])
+    k = 0
+    while k < n:
+        Z = rng.uniform(4, 50)
+        if rng.random() < ground:
+            X, Y = rng.uniform(-0.8, 0.8) * Z * 0.6, height
+        else:
+            X, Y = rng.uniform(-1, 1) * Z * 0.9, rng.uniform(-0.28, 0.02) * Z
+        P = np.array([X, Y, Z]); Q = R @ P + t
+        if Q[2] < 2:
+            continue
+        vals = np.array([f * P[0] / P[2] + cu, f * P[1] / P[2] + cv, f * Q[0] / Q[2] + cu, f * Q[1] / Q[2] + cv])
+        vals = np.round(vals + (rng.normal(0, noise, 4) if noise else 0))
+        if rng.random() < outliers:
+            vals[2:] += rng.integers(-40, 41, 2)
+        if not (0 <= vals[0] < W and 0 <= vals[2] < W and 0 <= vals[1] < H and 0 <= vals[3] < H):
+            continue
+        r = out[k]
+        r["u1p"], r["v1p"], r["u1c"], r["v1c"] = vals
+        r["i1p"] = r["i1c"] = k
+        k += 1
+    return out, np.array(tr)
