@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--noise", type=int, default=0, help="context runs: +-N grey levels of uniform noise on every frame "
                     "(many more, mostly unmatched features; the driver's line is noise 0, the BASELINE workload)")
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps steps each (0: as many as make the timed region >= 0.5 s, "
+                    "at least 3); every block is bracketed by the barrier + synchronize fence, the median block is reported")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",
@@ -233,11 +235,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or bool(os.environ.get("VH_BENCH_FORCE_DIST"))  # the env switch rehearses the RCCL plumbing on one GPU
+    if world != args.gpus and not os.environ.get("VH_BENCH_FORCE_DIST"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
     if use_dist:
         # RCCL only carries the barrier and the MAX-reduced timing: streams never exchange data
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")  # (only the single-process rehearsal lacks it; torch.distributed.run sets it)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # which device every rank really sits on: (rank, local rank, device index, PCI bus id), gathered to rank 0
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "pci_device_id": getattr(props, "pci_device_id", None),
+          "uuid": str(getattr(props, "uuid", ""))}
+    ranks_seen = [me]
+    if use_dist:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+        if rank == 0:
+            devs = {(r["pci_bus_id"], r["pci_device_id"], r["uuid"]) for r in ranks_seen}
+            assert len(ranks_seen) == world and (len(devs) == world or len(devs) == 1 and world == 1), \
+                f"ranks share a GPU: {ranks_seen}"
 
     pkg = entry.load_package()
     S, T = args.streams, args.frames
@@ -268,15 +286,31 @@ def main():
     for _ in range(args.warmup):
         step(k); k += 1
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):  # the timed region: no per-kernel events in it
-        step(k); k += 1
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+
+    def timed_block():
+        """EXACTLY --steps steps between two fences; MAX over ranks."""
+        nonlocal k
+        t0 = time.perf_counter()
+        for _ in range(args.steps):  # the timed region: no per-kernel events in it
+            step(k); k += 1
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # One block of K steps is ~0.1 s at the default K: a single scheduler hiccup would be 5 % of it.  So the
+    # block is repeated (every one under the same protocol) until >= 0.5 s have been timed, and the MEDIAN block
+    # is the one reported; all block times are in the line.
+    block_s = [timed_block()]
+    n_blocks = args.blocks if args.blocks > 0 else max(3, min(50, int(np.ceil(0.5 / max(block_s[0], 1e-6)))))
+    if use_dist:  # every rank must run the same number of blocks
+        nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev)
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+        n_blocks = int(nb.item())
+    while len(block_s) < n_blocks:
+        block_s.append(timed_block())
+    dt = float(np.median(block_s))
 
     # per-kernel device time: the same loop once more with HIP events recorded around every
     # launch on the stream it is launched on (two internal streams: detect of frame t+1 overlaps
@@ -379,6 +413,9 @@ def main():
             "metric": METRIC if args.workload == "kitti" else f"stereo frame-pairs/sec (detect+match), {W}x{H}; matches bit-exact",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "blocks": {"count": len(block_s), "steps_each": args.steps, "reported": "median", "seconds_each": [round(b, 5) for b in block_s],
+                       "timed_seconds_total": round(float(np.sum(block_s)), 4)},
+            "ranks_seen": ranks_seen,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["label"] + (f" + noise +-{NOISE}" if NOISE else ""),
                        "streams_per_gpu": S, "frames_in_hbm": T, "features_per_image": float(nfm.mean()),
