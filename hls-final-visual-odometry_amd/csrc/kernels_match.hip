@@ -225,6 +225,170 @@ __device__ __forceinline__ int32_t key_mode_of(int32_t class_count, int32_t wide
   return class_count <= VH_CLASS_POS_MAX && wide_keys < 2 ? KEY_W19 : KEY_64;
 }
 
+// Second half of the speculative searches.  A query whose winner over the walked region lies
+// outside its own window is searched again with the literal accept test of matcher.cpp:249, lanes
+// over candidates.  Up to VH_REDO_G such queries of a tile share ONE walk over the union of their
+// own regions: the candidate records are loaded once per group (round 2 walked once per query, and
+// that stream of 40 KB per query, not the arithmetic, is what made the speculative form lose on
+// images full of features without a partner), every lane tests its candidate against each query of
+// the group (descriptors and windows wave-uniform, in scalar registers).  Measured on MI355X (KITTI, S = 256,
+// speculative loops forced, k pairs/s at noise 0 / +-1 / +-2 grey levels; the tested loops: 101.9 / 67.2 / 48.5):
+// G = 1: 101.3 / 55.3 / 38.0, G = 2: 101.1 / 60.3 / 42.1, G = 4: 100.9 / 62.7 / 43.9, G = 8: 93.1* / 58.2 / 42.0
+// (* with the position tables of branch exp/position-tables).  Round 2's one-walk-per-query form: 51.9 / 34.0.
+#ifndef VH_REDO_G
+#define VH_REDO_G 2
+#endif
+struct RedoGroup {
+  uint32_t qd[VH_REDO_G][8];  // descriptors (wave-uniform)
+  us2 lo2[VH_REDO_G];         // window origins
+  int32_t lane[VH_REDO_G], qi[VH_REDO_G], n;
+  int32_t umin, umax, vmin, vmax;
+};
+// Takes up to VH_REDO_G (lane, query slot) pairs off the ballots `todo[Q]`; false when none is left.
+template <int Q>
+__device__ __forceinline__ bool redo_take(uint64_t (&todo)[Q], const uint4 (&a0)[Q], const uint4 (&a1)[Q], const uint32_t (&uv1)[Q],
+                                          int32_t radius, int32_t rv, RedoGroup &g) {
+  g.n = 0; g.umin = g.vmin = 0x7FFFFFFF; g.umax = g.vmax = -1;
+#pragma unroll
+  for (int32_t k = 0; k < VH_REDO_G; k++) {
+    int32_t fl = -1, fq = 0;
+#pragma unroll
+    for (int32_t qi = 0; qi < Q; qi++)
+      if (fl < 0 && todo[qi]) { fl = (int32_t)__builtin_ctzll(todo[qi]); fq = qi; todo[qi] &= todo[qi] - 1; }
+    if (fl < 0) break;  // wave-uniform
+    uint4 x0 = a0[0], x1 = a1[0];
+    uint32_t xu = uv1[0];
+#pragma unroll
+    for (int32_t qi = 1; qi < Q; qi++) if (fq == qi) { x0 = a0[qi]; x1 = a1[qi]; xu = uv1[qi]; }
+    g.qd[k][0] = __builtin_amdgcn_readlane(x0.x, fl); g.qd[k][1] = __builtin_amdgcn_readlane(x0.y, fl);
+    g.qd[k][2] = __builtin_amdgcn_readlane(x0.z, fl); g.qd[k][3] = __builtin_amdgcn_readlane(x0.w, fl);
+    g.qd[k][4] = __builtin_amdgcn_readlane(x1.x, fl); g.qd[k][5] = __builtin_amdgcn_readlane(x1.y, fl);
+    g.qd[k][6] = __builtin_amdgcn_readlane(x1.z, fl); g.qd[k][7] = __builtin_amdgcn_readlane(x1.w, fl);
+    const uint32_t quv1 = __builtin_amdgcn_readlane(xu, fl);
+    const int32_t u1 = (int32_t)(quv1 & 0xFFFF), v1 = (int32_t)(quv1 >> 16);
+    g.lo2[k] = us2{(unsigned short)(u1 - radius), (unsigned short)(v1 - rv)};
+    g.lane[k] = fl; g.qi[k] = fq; g.n = k + 1;
+    g.umin = min(g.umin, u1); g.umax = max(g.umax, u1); g.vmin = min(g.vmin, v1); g.vmax = max(g.vmax, v1);
+  }
+  return g.n > 0;
+}
+
+// What a tile hands to finish_tile: per query slot the minimum key over the walked region, joined over
+// the phases (SAD << 32 | class-relative position, ~0: none), and the query itself.
+template <int Q> struct TileOut {
+  uint64_t k[Q];
+  uint4 a0[Q], a1[Q];
+  uint32_t uv1[Q];
+  int32_t qpos[Q];  // the query's bin-order position
+  bool valid[Q];
+};
+
+// The end of a tile, shared by every key encoding and by both kinds of pass (one copy of this code per
+// kernel: inside the KM-templated tile functions it would be there six times).  Speculative form: the
+// winner over the walked region is tested against the query's own window, and the queries that fail are
+// searched again in groups (RedoGroup above).  The results go to the table as the reference's findMatch
+// returns them: best[query's feature index] = winner's feature index.  (Round 3 also built the tables in
+// position space -- entries = bin-order positions, stored at the queries' own positions, whole rows per
+// store, the chain followed in position space: branch exp/position-tables.  The table writes fell from
+// 14x to 1x their payload, but the chain then needs eleven gathers and a scattered record per circle
+// instead of six gathers: 126 vs 65 us, and the step 99.1 k vs 102.0 k pairs/s on the same box.  The
+// 4-byte scatter below costs no time; it stays.)
+template <int Q, int P, bool SPEC, bool FLOW>
+__device__ __forceinline__ void finish_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset, int32_t cset,
+                                            int32_t c, int32_t pbase, int32_t pcnt, const TileOut<Q> &o,
+                                            int32_t *__restrict__ best, int32_t *__restrict__ redo_count) {
+  constexpr int L = 64 / P;
+  const int32_t lane = threadIdx.x & 63, ph = lane / L;
+  const uint32_t *__restrict__ cuv = s.s_uv + (int64_t)cset * s.cap;
+  const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
+  const int32_t *__restrict__ cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
+  const int32_t rv = FLOW ? a.radius : a.disp_tol;
+  const us2 span2 = {(unsigned short)(2 * a.radius), (unsigned short)(2 * rv)};
+  const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
+  const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
+  int32_t *__restrict__ tbl = best + ((int64_t)stream * 4 + a.pass[pass].slot) * s.cap;
+  int32_t res[Q];
+  uint64_t todo[Q];
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    res[qi] = -1;  // no candidate accepted
+    bool fail = false;
+    if (o.valid[qi] && ph == 0 && o.k[qi] != ~0ull) {
+      // (a winner is never one of the copies past the end of a run -- the original has the same SAD at a lower
+      //  position -- so its position lies inside the class)
+      int32_t wp = (int32_t)(uint32_t)o.k[qi];
+      VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
+      res[qi] = pbase + wp;
+      if (SPEC) {  // the winner over the walked region: inside this query's own window?
+        const int32_t u1 = o.uv1[qi] & 0xFFFF, v1 = o.uv1[qi] >> 16;
+        const us2 lo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - rv)};
+        const us2 t = as_us2(cuv[res[qi]]) - lo2;
+        const us2 m = __builtin_elementwise_min(t, span2);
+        fail = as_u32(t) != as_u32(m);
+      }
+    }
+    todo[qi] = SPEC ? __ballot(fail) : 0ull;
+  }
+  if (SPEC) {
+    int32_t nfail = 0;
+#pragma unroll
+    for (int32_t qi = 0; qi < Q; qi++) nfail += (int32_t)__popcll(todo[qi]);
+    if (nfail) {  // wave-uniform
+      VH_STAT(FLOW ? 7 : 10, nfail);
+      if (lane == 0) atomicAdd(redo_count, nfail);
+      RedoGroup g;
+      while (redo_take<Q>(todo, o.a0, o.a1, o.uv1, a.radius, rv, g)) {
+        uint64_t kk[VH_REDO_G];
+#pragma unroll
+        for (int32_t k = 0; k < VH_REDO_G; k++) kk[k] = ~0ull;
+        if (FLOW) {
+          const auto bin_of = [&](int32_t x, int32_t nb) -> int32_t {
+            const uint32_t xx = (uint32_t)max(x, 0);
+            return min((int32_t)(s.binsize == 1 ? xx : __umulhi(xx, s.inv_binsize)), nb - 1);
+          };
+          // the union of the group's own bin ranges (matcher.cpp:237-240)
+          walk_region<false, true>(s, cbs, cuv, cdesc, c, bin_of(g.umin - a.radius, s.ubn), bin_of(g.umax + a.radius, s.ubn),
+                                   bin_of(g.vmin - rv, s.vbn), bin_of(g.vmax + rv, s.vbn), 0, 0, 0, 0,
+            [&](int32_t, int32_t, int32_t, int32_t, int32_t pl, uint32_t gu, const uint4 &g0, const uint4 &g1) {
+#pragma unroll
+              for (int32_t k = 0; k < VH_REDO_G; k++)
+                if (k < g.n) kk[k] = min(kk[k], tested_key_uniform_query(g.qd[k], g.lo2[k], span2, gu, g0, g1, (uint32_t)(pl - pbase)));
+            });
+        } else {
+          // the union of the group's own rows [v - tol, v + tol]
+          const int32_t *__restrict__ crs = s.row_start + (int64_t)cset * (4 * s.H + 1);
+          const int32_t *__restrict__ cpos = s.r_pos + (int64_t)cset * s.cap;
+          const int32_t x0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + max(g.vmin - rv, 0)]);
+          const int32_t x1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + min(g.vmax + rv, s.H - 1) + 1]);
+          for (int32_t x = x0 + lane; x < x1; x += 64) {
+            int32_t cp = cpos[x];
+            VH_CHECK_RANGE(s, 3, cp, pbase, pbase + pcnt);
+            const uint32_t gu = cuv[cp];
+            const uint4 g0 = cdesc[2 * (int64_t)cp], g1 = cdesc[2 * (int64_t)cp + 1];
+#pragma unroll
+            for (int32_t k = 0; k < VH_REDO_G; k++)
+              if (k < g.n) kk[k] = min(kk[k], tested_key_uniform_query(g.qd[k], g.lo2[k], span2, gu, g0, g1, (uint32_t)(cp - pbase)));
+          }
+        }
+#pragma unroll
+        for (int32_t k = 0; k < VH_REDO_G; k++)
+          if (k < g.n) {
+            const uint64_t kf = wave_min_u64(kk[k]);
+            int32_t wp = (int32_t)(uint32_t)kf;
+            if (kf != ~0ull) VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
+            const int32_t r = kf == ~0ull ? -1 : pbase + wp;
+#pragma unroll
+            for (int32_t qi = 0; qi < Q; qi++) if (lane == g.lane[k] && g.qi[k] == qi) res[qi] = r;
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++)
+    if (o.valid[qi] && ph == 0)  // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
+      tbl[qidx[o.qpos[qi]]] = res[qi] < 0 ? 0 : cidx[res[qi]];
+}
+
 // One tile of the flow search.
 //
 // A tile is T = 64*Q/P consecutive bin-ordered queries of one class.  The wave's
@@ -268,17 +432,15 @@ __device__ __forceinline__ int32_t key_mode_of(int32_t class_count, int32_t wide
 template <int Q, int P, int KM, bool SPEC>
 __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream,
                                           int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c,
-                                          int32_t pbase, int32_t pcnt, uint4 *wD, uint32_t *wU, int32_t *__restrict__ best, int32_t *__restrict__ redo_count) {
+                                          int32_t pbase, int32_t pcnt, uint4 *wD, uint32_t *wU, TileOut<Q> &out) {
   constexpr int L = 64 / P;
   static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile (row-wise window reduction)");
   constexpr int TRIP = 2 * P;  // candidates per trip: two steps, joined by one v_min3_u32 per query
   const int32_t lane = threadIdx.x & 63, ph = lane / L, l = lane % L;
   const uint32_t *__restrict__ quv = s.s_uv + (int64_t)qset * s.cap;
   const uint4 *__restrict__ qdesc = (const uint4 *)(s.s_desc + (int64_t)qset * s.cap * 8);
-  const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
   const uint32_t *__restrict__ cuv = s.s_uv + (int64_t)cset * s.cap;
   const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
-  const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
   const int32_t *__restrict__ cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
   const int32_t rv = a.pass[pass].flow ? a.radius : a.disp_tol;
 
@@ -400,65 +562,14 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
         run(std::integral_constant<int, 2>{}, jend);
       }
     });
-  uint64_t kfin[Q];  // SAD << 32 | relative position, ~0: none
-  bool redo[Q];
+  // join the phases: lanes l, l+L, l+2L, .. hold partial minima of the same query
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
-    // join the phases: lanes l, l+L, l+2L, .. hold partial minima of the same query
     uint64_t k = key_to_64<KM>(best_key[qi]);
 #pragma unroll
     for (int32_t d = L; d < 64; d <<= 1) k = min(k, shfl_xor_u64(k, d));
-    kfin[qi] = k;
-    redo[qi] = false;
-    if (SPEC && valid[qi] && ph == 0 && k != ~0ull) {
-      // the winner over the union region: inside this query's own window?
-      // (a winner is never one of the copies past the end of a run -- the original has the same SAD at a lower
-      //  position -- so its position lies inside the class)
-      int32_t wp = (int32_t)(uint32_t)k;
-      VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
-      const us2 t = as_us2(cuv[pbase + wp]) - lo2[qi];
-      const us2 m = __builtin_elementwise_min(t, span2);
-      redo[qi] = as_u32(t) != as_u32(m);
-    }
-  }
-  if (SPEC) {
-#pragma unroll
-    for (int32_t qi = 0; qi < Q; qi++) {
-      uint64_t todo = __ballot(redo[qi]);
-      if (todo) { VH_STAT(7, __popcll(todo)); if (lane == 0) atomicAdd(redo_count, (int32_t)__popcll(todo)); }
-      while (todo) {  // wave-uniform
-        const int32_t fl = (int32_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        uint32_t qd[8];
-        qd[0] = __builtin_amdgcn_readlane(a0[qi].x, fl); qd[1] = __builtin_amdgcn_readlane(a0[qi].y, fl);
-        qd[2] = __builtin_amdgcn_readlane(a0[qi].z, fl); qd[3] = __builtin_amdgcn_readlane(a0[qi].w, fl);
-        qd[4] = __builtin_amdgcn_readlane(a1[qi].x, fl); qd[5] = __builtin_amdgcn_readlane(a1[qi].y, fl);
-        qd[6] = __builtin_amdgcn_readlane(a1[qi].z, fl); qd[7] = __builtin_amdgcn_readlane(a1[qi].w, fl);
-        // the literal search for this one query by the whole wave, lanes over candidates,
-        // over the query's own bin range (matcher.cpp:237-249)
-        const uint32_t quv1 = __builtin_amdgcn_readlane(uv1[qi], fl);
-        const int32_t u1 = (int32_t)(quv1 & 0xFFFF), v1 = (int32_t)(quv1 >> 16);
-        const us2 qlo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - rv)};
-        uint64_t k = ~0ull;
-        walk_region<false, true>(s, cbs, cuv, cdesc, c, bin_of(u1 - a.radius, s.ubn), bin_of(u1 + a.radius, s.ubn),
-                                 bin_of(v1 - rv, s.vbn), bin_of(v1 + rv, s.vbn), 0, 0, 0, 0,
-          [&](int32_t, int32_t, int32_t, int32_t, int32_t pl, uint32_t gu, const uint4 &g0, const uint4 &g1) {
-            k = min(k, tested_key_uniform_query(qd, qlo2, span2, gu, g0, g1, (uint32_t)(pl - pbase)));
-          });
-        k = wave_min_u64(k);
-        if (lane == fl) kfin[qi] = k;
-      }
-    }
-  }
-#pragma unroll
-  for (int32_t qi = 0; qi < Q; qi++) {
-    if (valid[qi] && ph == 0) {
-      // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      int32_t wp = (kfin[qi] == ~0ull) ? 0 : (int32_t)(uint32_t)kfin[qi];
-      if (kfin[qi] != ~0ull) VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
-      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + wp];
-      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[q0 + L * qi + l]] = r;
-    }
+    out.k[qi] = k; out.a0[qi] = a0[qi]; out.a1[qi] = a1[qi]; out.uv1[qi] = uv1[qi]; out.valid[qi] = valid[qi];
+    out.qpos[qi] = valid[qi] ? q0 + L * qi + l : q0;
   }
 }
 
@@ -476,9 +587,11 @@ __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a,
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
     const int32_t km = key_mode_of(pend - pbase, a.wide_keys);
-    if (km == KEY_HI16) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best, redo_count);
-    else if (km == KEY_W19) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best, redo_count);
-    else flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, best, redo_count);
+    TileOut<VH_FLOW_Q> out;
+    if (km == KEY_HI16) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, out);
+    else if (km == KEY_W19) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, out);
+    else flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, out);
+    finish_tile<VH_FLOW_Q, VH_FLOW_P, SPEC, true>(s, a, pass, stream, qset, cset, c, pbase, pend - pbase, out, best, redo_count);
   }
 }
 
@@ -503,7 +616,7 @@ __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a,
 template <int Q, int P, int KM, bool SPEC>
 __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
                                           int32_t cset, int32_t q0, int32_t q1, int32_t c, int32_t pbase, int32_t pcnt, uint4 *wD,
-                                          uint32_t *wU, uint32_t *wV, int32_t *__restrict__ best, int32_t *__restrict__ redo_count) {
+                                          uint32_t *wU, uint32_t *wV, TileOut<Q> &out) {
   constexpr int L = 64 / P;
   static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile");
   constexpr int TRIP = 2 * P;
@@ -516,8 +629,6 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
   const int32_t *__restrict__ cpos = s.r_pos + (int64_t)cset * s.cap;
   const uint32_t *__restrict__ cuv = s.s_uv + (int64_t)cset * s.cap;
   const uint4 *__restrict__ cdesc = (const uint4 *)(s.s_desc + (int64_t)cset * s.cap * 8);
-  const int32_t *__restrict__ qidx = s.s_idx + (int64_t)qset * s.cap;
-  const int32_t *__restrict__ cidx = s.s_idx + (int64_t)cset * s.cap;
 
   bool valid[Q];
   uint4 a0[Q], a1[Q];
@@ -582,71 +693,20 @@ __device__ __forceinline__ void rows_tile(const VhSets &s, const VhMatchArgs &a,
       rd += TRIP; ru += TRIP; rv += TRIP;
     }
   }
-  // join the phases; speculative form: test the winner against the query's own window, search again where it fails
-  uint64_t kfin[Q];  // SAD << 32 | relative position, ~0: none
-  bool redo[Q];
+  // join the phases
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
     uint64_t k = key_to_64<KM>(best_key[qi]);
 #pragma unroll
     for (int32_t d = L; d < 64; d <<= 1) k = min(k, shfl_xor_u64(k, d));
-    kfin[qi] = k;
-    redo[qi] = false;
-    if (SPEC && valid[qi] && ph == 0 && k != ~0ull) {
-      // (a winner is never one of the copies past the end of a run -- the original has the same SAD at a lower
-      //  position -- so its position lies inside the class)
-      int32_t wp = (int32_t)(uint32_t)k;
-      VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
-      const us2 t = as_us2(cuv[pbase + wp]) - lo2[qi];
-      const us2 m = __builtin_elementwise_min(t, span2);
-      redo[qi] = as_u32(t) != as_u32(m);
-    }
-  }
-#pragma unroll
-  for (int32_t qi = 0; qi < Q; qi++) {
-    uint64_t todo = SPEC ? __ballot(redo[qi]) : 0;
-    if (todo) { VH_STAT(10, __popcll(todo)); if (lane == 0) atomicAdd(redo_count, (int32_t)__popcll(todo)); }
-    while (todo) {  // wave-uniform
-      const int32_t fl = (int32_t)__builtin_ctzll(todo);
-      todo &= todo - 1;
-      uint32_t qd[8];
-      qd[0] = __builtin_amdgcn_readlane(a0[qi].x, fl); qd[1] = __builtin_amdgcn_readlane(a0[qi].y, fl);
-      qd[2] = __builtin_amdgcn_readlane(a0[qi].z, fl); qd[3] = __builtin_amdgcn_readlane(a0[qi].w, fl);
-      qd[4] = __builtin_amdgcn_readlane(a1[qi].x, fl); qd[5] = __builtin_amdgcn_readlane(a1[qi].y, fl);
-      qd[6] = __builtin_amdgcn_readlane(a1[qi].z, fl); qd[7] = __builtin_amdgcn_readlane(a1[qi].w, fl);
-      // the literal search for this one query by the whole wave, lanes over the
-      // candidates of its own rows [v1-tol, v1+tol]
-      const uint32_t quv1 = __builtin_amdgcn_readlane(uv1[qi], fl);
-      const int32_t u1 = (int32_t)(quv1 & 0xFFFF), v1 = (int32_t)(quv1 >> 16);
-      const us2 qlo2 = {(unsigned short)(u1 - a.radius), (unsigned short)(v1 - a.disp_tol)};
-      const int32_t x0 = __builtin_amdgcn_readfirstlane(crs[c * s.H + max(v1 - a.disp_tol, 0)]);
-      const int32_t x1 = __builtin_amdgcn_readfirstlane(crs[c * s.H + min(v1 + a.disp_tol, s.H - 1) + 1]);
-      uint64_t k = ~0ull;
-      for (int32_t x = x0 + lane; x < x1; x += 64) {
-        int32_t cp = cpos[x];
-        VH_CHECK_RANGE(s, 3, cp, pbase, pbase + pcnt);
-        k = min(k, tested_key_uniform_query(qd, qlo2, span2, cuv[cp], cdesc[2 * (int64_t)cp], cdesc[2 * (int64_t)cp + 1], (uint32_t)(cp - pbase)));
-      }
-      k = wave_min_u64(k);
-      if (lane == fl) kfin[qi] = k;
-    }
-  }
-#pragma unroll
-  for (int32_t qi = 0; qi < Q; qi++) {
-    if (valid[qi] && ph == 0) {
-      // min_ind defaults to 0 when no candidate was accepted (matcher.cpp:221)
-      int32_t wp = (kfin[qi] == ~0ull) ? 0 : (int32_t)(uint32_t)kfin[qi];
-      if (kfin[qi] != ~0ull) VH_CHECK_RANGE(s, 7, wp, 0, pcnt);
-      const int32_t r = (kfin[qi] == ~0ull) ? 0 : cidx[pbase + wp];
-      best[((int64_t)stream * 4 + a.pass[pass].slot) * s.cap + qidx[qp[qi]]] = r;
-    }
+    out.k[qi] = k; out.a0[qi] = a0[qi]; out.a1[qi] = a1[qi]; out.uv1[qi] = uv1[qi]; out.valid[qi] = valid[qi];
+    out.qpos[qi] = qp[qi];
   }
 }
 
 template <bool SPEC>
 __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream, int32_t qset,
-                                          int32_t cset, uint4 *wD, uint32_t *wU, uint32_t *wV, int32_t *__restrict__ best,
-                                          int32_t *__restrict__ redo_count) {
+                                          int32_t cset, uint4 *wD, uint32_t *wU, uint32_t *wV, int32_t *__restrict__ best, int32_t *__restrict__ redo_count) {
   const int32_t nrow = 4 * s.H;
   const int32_t *__restrict__ qrs = s.row_start + (int64_t)qset * (nrow + 1);
   // tile -> (class, query range): classes are contiguous in row order
@@ -667,9 +727,11 @@ __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a,
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
     const int32_t km = key_mode_of(pend - pbase, a.wide_keys);
-    if (km == KEY_HI16) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, best, redo_count);
-    else if (km == KEY_W19) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, best, redo_count);
-    else rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, best, redo_count);
+    TileOut<VH_FLOW_Q> out;
+    if (km == KEY_HI16) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, out);
+    else if (km == KEY_W19) rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, out);
+    else rows_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, wV, out);
+    finish_tile<VH_FLOW_Q, VH_FLOW_P, SPEC, false>(s, a, pass, stream, qset, cset, c, pbase, pend - pbase, out, best, redo_count);
   }
 }
 

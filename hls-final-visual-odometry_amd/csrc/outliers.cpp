@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <numeric>
 #include <vector>
@@ -40,7 +41,9 @@ inline bool turns_ccw(Pt p, Pt q, Pt r) {
   const float det = ux * vy - uy * vx;
   if (det == 0) return false;
   const float size = (ux * ux + uy * uy) + (vx * vx + vy * vy);
-  if (static_cast<double>(std::fabs(size / det)) > 1e14) return false;
+  // |size / det| > 1e14 is impossible when |det| >= 1 and size <= 9e13 (the quotient cannot exceed size):
+  // on pixel coordinates det is a non-zero integer, so the division is only done for exotic inputs
+  if (!(std::fabs(det) >= 1.0f && size <= 9e13f) && static_cast<double>(std::fabs(size / det)) > 1e14) return false;
   return det > 0;
 }
 
@@ -55,20 +58,35 @@ inline bool circum_offset(Pt a, Pt b, Pt c, double &ox, double &oy) {
   return (bl > 0 || bl < 0) && (cl > 0 || cl < 0) && (det > 0 || det < 0);
 }
 
+// Working storage of one triangulation.  One instance per host thread (thread_local below) and reused from call
+// to call: a fresh std::vector set per call cost ~15 % of the call in allocations and first-touch page faults.
+struct Scratch {
+  std::vector<Pt> pts;
+  std::vector<int32_t> tri, twin, prev, next, edge_of, bucket, pending, order, order2, votes;
+  std::vector<uint32_t> key;
+};
+
 class SweepHull {
  public:
-  explicit SweepHull(const std::vector<Pt> &pts) : p_(pts), n_(static_cast<int32_t>(pts.size())) {}
+  SweepHull(Scratch &w, int32_t n) : w_(w), p_(w.pts), n_(n), tri_(w.tri), twin_(w.twin), prev_(w.prev), next_(w.next),
+                                     edge_of_(w.edge_of), bucket_(w.bucket), pending_(w.pending) {}
 
-  // triangle corners, three per triangle, in the reference's order
-  const std::vector<int32_t> &run() {
+  // triangle corners, three per triangle, in the reference's order: tri()[0 .. size())
+  void run() {
+    ntri_ = 0; ntwin_ = 0;
     if (n_ >= 3) sweep();
-    return tri_;
   }
+  const int32_t *tri() const { return tri_.data(); }
+  size_t size() const { return static_cast<size_t>(ntri_); }
 
  private:
+  Scratch &w_;
   const std::vector<Pt> &p_;
   const int32_t n_;
-  std::vector<int32_t> tri_, twin_, prev_, next_, edge_of_, bucket_, pending_;
+  // tri_/twin_ are used as arrays of 6 n slots (a triangulation of n points has fewer than 2 n triangles) with their
+  // own lengths ntri_/ntwin_ -- the reference's triangles_cnt / halfedges_cnt
+  std::vector<int32_t> &tri_, &twin_, &prev_, &next_, &edge_of_, &bucket_, &pending_;
+  int32_t ntri_ = 0, ntwin_ = 0;
   int32_t hull_entry_ = 0, buckets_ = 0;
   Pt origin_{0, 0};
 
@@ -86,9 +104,8 @@ class SweepHull {
   // delaunator.cpp:585-603
   void pair_up(int32_t a, int32_t b) {
     const auto set = [this](int32_t at, int32_t to) {
-      const int32_t size = static_cast<int32_t>(twin_.size());
-      if (at == size) twin_.push_back(to);
-      else if (at < size) twin_[at] = to;
+      if (at == ntwin_) twin_[ntwin_++] = to;
+      else if (at < ntwin_) twin_[at] = to;
     };
     set(a, b);
     if (b != kNone) set(b, a);
@@ -96,8 +113,9 @@ class SweepHull {
 
   // delaunator.cpp:566-583
   int32_t emit(int32_t i0, int32_t i1, int32_t i2, int32_t a, int32_t b, int32_t c) {
-    const int32_t t = static_cast<int32_t>(tri_.size());
-    tri_.push_back(i0); tri_.push_back(i1); tri_.push_back(i2);
+    const int32_t t = ntri_;
+    tri_[t] = i0; tri_[t + 1] = i1; tri_[t + 2] = i2;
+    ntri_ += 3;
     pair_up(t, a); pair_up(t + 1, b); pair_up(t + 2, c);
     return t;
   }
@@ -159,18 +177,42 @@ class SweepHull {
     }
     const float w = hi_x - lo_x, h = hi_y - lo_y, span = w * w + h * h;
     const Pt mid{(lo_x + hi_x) / 2, (lo_y + hi_y) / 2};
-    std::vector<float> far(n_);
+    std::vector<uint32_t> &key = w_.key;
+    std::vector<int32_t> &order = w_.order;
+    key.resize(n_); order.resize(n_);
     int32_t s0 = kNone, s1 = kNone, s2 = kNone;
     float least = std::numeric_limits<float>::infinity();
+    bool plain = true;  // every distance a non-negative, non-NaN float: its bit pattern orders like its value
     for (int32_t i = 0; i < n_; i++) {
-      const float dx = p_[i].x - mid.x, dy = p_[i].y - mid.y;
-      far[i] = dx * dx + dy * dy;
-      if (far[i] < least) { s0 = i; least = far[i]; }
+      const float dx = p_[i].x - mid.x, dy = p_[i].y - mid.y, far = dx * dx + dy * dy;
+      if (far < least) { s0 = i; least = far; }
+      uint32_t bits;
+      static_assert(sizeof(bits) == sizeof(far), "float is 32 bits");
+      std::memcpy(&bits, &far, sizeof(bits));
+      key[i] = bits;
+      plain = plain && far >= 0.0f;  // (false for NaN)
+      order[i] = i;
     }
-    // the reference's insertion sort (:409-424) is stable; so is this
-    std::vector<int32_t> order(n_);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&far](int32_t a, int32_t b) { return far[a] < far[b]; });
+    // the reference's insertion sort (:409-424) is stable; so are both of these
+    if (plain && n_ >= 256) {
+      // least-significant-digit radix sort on the distance's bit pattern, three 11-bit digits
+      std::vector<int32_t> &tmp = w_.order2;
+      tmp.resize(n_);
+      int32_t *src = order.data(), *dst = tmp.data();
+      for (int32_t pass = 0; pass < 3; pass++) {
+        const int32_t shift = 11 * pass;
+        uint32_t count[2048] = {0};
+        for (int32_t i = 0; i < n_; i++) count[(key[i] >> shift) & 2047u]++;
+        uint32_t run = 0;
+        for (uint32_t &c : count) { const uint32_t k = c; c = run; run += k; }
+        for (int32_t i = 0; i < n_; i++) { const int32_t v = src[i]; dst[count[(key[v] >> shift) & 2047u]++] = v; }
+        std::swap(src, dst);
+      }
+      if (src != order.data()) std::memcpy(order.data(), src, sizeof(int32_t) * static_cast<size_t>(n_));
+    } else {
+      const auto far_of = [&key](int32_t i) { float f; std::memcpy(&f, &key[i], sizeof(f)); return f; };
+      std::stable_sort(order.begin(), order.end(), [&far_of](int32_t a, int32_t b) { return far_of(a) < far_of(b); });
+    }
     if (s0 == kNone) return;
 
     // :240-262 seed triangle
@@ -202,7 +244,7 @@ class SweepHull {
     buckets_ = static_cast<int32_t>(std::ceil(std::sqrt(static_cast<double>(n_))));
     bucket_.assign(buckets_, kNone);
     prev_.assign(n_, 0); next_.assign(n_, 0); edge_of_.assign(n_, 0);
-    tri_.reserve(6 * static_cast<size_t>(n_)); twin_.reserve(6 * static_cast<size_t>(n_));
+    if (tri_.size() < 6 * static_cast<size_t>(n_)) { tri_.resize(6 * static_cast<size_t>(n_)); twin_.resize(6 * static_cast<size_t>(n_)); }
     hull_entry_ = s0;
     next_[s0] = prev_[s2] = s1;
     next_[s1] = prev_[s0] = s2;
@@ -213,9 +255,14 @@ class SweepHull {
     bucket_[bucket_of(p_[s2])] = s2;
     emit(s0, s1, s2, kNone, kNone, kNone);
 
-    const auto coincides = [span](Pt a, Pt b) {  // Point::equal, delaunator.hpp:64-71
-      const float dx = b.x - a.x, dy = b.y - a.y;
-      return static_cast<double>((dx * dx + dy * dy) / span) < 1e-20;
+    // Point::equal, delaunator.hpp:64-71: (d2 / span) < 1e-20 in double.  d2 > span * 1e-18 (a normal float) puts
+    // the quotient far above 1e-20 without dividing; anything else takes the literal form.
+    const float span_eps = span * 1e-18f;
+    const bool span_eps_ok = span_eps >= std::numeric_limits<float>::min() && std::isfinite(span_eps);
+    const auto coincides = [span, span_eps, span_eps_ok](Pt a, Pt b) {
+      const float dx = b.x - a.x, dy = b.y - a.y, d2 = dx * dx + dy * dy;
+      if (span_eps_ok && d2 > span_eps) return false;
+      return static_cast<double>(d2 / span) < 1e-20;
     };
 
     // :303-404; the three seeds are offered to the hull like every other point
@@ -282,18 +329,21 @@ extern "C" int32_t vh_remove_outliers_pm(vh_p_match *pm, int32_t n, int32_t *n_o
   if (!n_out || n < 0 || (n > 0 && !pm)) return VH_ERR_INVALID_ARG;
   *n_out = n;
   if (n <= 3) return VH_OK;  // remove_outliers.cpp:6-7
-  std::vector<Pt> pts(static_cast<size_t>(n));
-  for (int32_t i = 0; i < n; i++) pts[i] = Pt{pm[i].u1c, pm[i].v1c};
-  SweepHull hull(pts);
-  const std::vector<int32_t> &tri = hull.run();
-  std::vector<int32_t> votes(static_cast<size_t>(n), 0);
+  thread_local Scratch scratch;
+  scratch.pts.resize(static_cast<size_t>(n));
+  for (int32_t i = 0; i < n; i++) scratch.pts[i] = Pt{pm[i].u1c, pm[i].v1c};
+  SweepHull hull(scratch, n);
+  hull.run();
+  const int32_t *tri = hull.tri();
+  std::vector<int32_t> &votes = scratch.votes;
+  votes.assign(static_cast<size_t>(n), 0);
   const float tol = 5;  // hard-coded in the reference (:34), not parameters::outlier_flow_tolerance
   const auto flow_agrees = [pm, tol](int32_t a, int32_t b) {
     const float au = pm[a].u1c - pm[a].u1p, av = pm[a].v1c - pm[a].v1p;
     const float bu = pm[b].u1c - pm[b].u1p, bv = pm[b].v1c - pm[b].v1p;
     return std::fabs(au - bu) + std::fabs(av - bv) < tol ? 1 : 0;
   };
-  for (size_t t = 0; t + 2 < tri.size(); t += 3) {
+  for (size_t t = 0; t + 2 < hull.size(); t += 3) {
     const int32_t a = tri[t], b = tri[t + 1], c = tri[t + 2];
     const int32_t ab = flow_agrees(a, b), bc = flow_agrees(b, c), ac = flow_agrees(a, c);
     votes[a] += ab + ac;
