@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,12 @@ struct ProfEntry {
   double ms = 0;
   int64_t launches = 0;
 };
+
+uint32_t lfsr_next(uint32_t x);
+// Matcher::bucketFeatures (matcher.cpp:140-187) on the records pm[0, n): the selected records are written to
+// out (at most out_cap of them) in the reference's order; returns how many the reference would keep.
+int32_t bucket_records(const vh_p_match *pm, int32_t n, int32_t max_features, float bw, float bh, vh_p_match *out, int32_t out_cap,
+                       std::vector<int32_t> &work);
 
 struct Group {
   vh_params p{};
@@ -144,6 +151,7 @@ struct Group {
     for (int k = 0; k < 2; k++) if (ev_stage[k]) (void)hipEventDestroy(ev_stage[k]);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_down) (void)hipEventDestroy(ev_down);
+    for (auto &sl : post_slot) if (sl.ev) (void)hipEventDestroy(sl.ev);
     if (down_stream) (void)hipStreamDestroy(down_stream);
     for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); if (ev_stats[k]) (void)hipEventDestroy(ev_stats[k]); }
     if (h_stats) (void)hipHostFree(h_stats);
@@ -190,6 +198,14 @@ struct Group {
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
     d_ego_rand = nullptr; d_ego_ok = nullptr; d_ego_xyz = nullptr; d_ego_tr = nullptr; ego_rand_n = 0;
     d_mono_scratch = nullptr; d_mono_rand = nullptr; mono_rand_n = 0;
+    d_bucket = nullptr; d_bcnt = nullptr; bcap = 0; d_post_rand = nullptr; post_rand_n = 0; d_post_xyz = nullptr; d_post_tr = nullptr; d_post_ok = nullptr;
+    if (h_bucket) { (void)hipHostFree(h_bucket); h_bucket = nullptr; }
+    if (h_bcnt) { (void)hipHostFree(h_bcnt); h_bcnt = nullptr; }
+    for (auto &sl : post_slot) {
+      if (sl.h_pm) { (void)hipHostFree(sl.h_pm); sl.h_pm = nullptr; }
+      if (sl.h_cnt) { (void)hipHostFree(sl.h_cnt); sl.h_cnt = nullptr; }
+      sl.cap_ps = 0; sl.pending = false;
+    }
     if (h_overflow) { (void)hipHostFree(h_overflow); h_overflow = nullptr; }
     allocated = false;
   }
@@ -788,6 +804,128 @@ struct Group {
     return VH_OK;
   }
 
+  // ---- the steps after matching, pipelined -----------------------------------
+  // What the reference's loop does after Matcher::matching -- removeOutliers (src/matcher.cpp:108),
+  // bucketFeatures (src/viso_stereo.cpp:41-43 -> matcher.cpp:140-187), estimateMotion
+  // (src/viso_stereo.cpp:49-51) -- for every stream of the group: post_begin() starts the download of the
+  // step's match lists into one of two page-locked slots and returns; post_finish() runs the Delaunay
+  // vote and the bucketing of a begun step on `threads` host threads (one stream per task), uploads the
+  // bucketed lists (a few hundred records per stream) and runs the batched egomotion kernel on them.
+  // A caller that issues step t+1 before finishing step t has the host work of t running beside the
+  // GPU work of t+1.
+  struct PostSlot {
+    vh_p_match *h_pm = nullptr;   // page-locked [S][cap_ps]
+    int32_t *h_cnt = nullptr;     // page-locked [S] (+ [S] overflow flags)
+    int32_t cap_ps = 0, width = 0, method = -1;  // allocated / downloaded records per stream
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+  } post_slot[2];
+  int64_t post_seq = 0;
+  vh_p_match *h_bucket = nullptr, *d_bucket = nullptr;  // [S][bcap]
+  int32_t *h_bcnt = nullptr, *d_bcnt = nullptr, bcap = 0;
+  int32_t *d_post_rand = nullptr; size_t post_rand_n = 0;
+  double *d_post_xyz = nullptr, *d_post_tr = nullptr; int32_t *d_post_ok = nullptr;
+
+  int32_t post_begin(int32_t cap_ps) {
+    if (cap_ps < 1) return VH_ERR_INVALID_ARG;
+    if (!allocated || last_method < 0) return VH_ERR_STATE;
+    PostSlot &sl = post_slot[post_seq & 1];
+    cap_ps = std::min(cap_ps, mcap);
+    if (sl.cap_ps < cap_ps) {
+      if (sl.h_pm) { VH_HIP(hipHostFree(sl.h_pm)); sl.h_pm = nullptr; }
+      VH_HIP(hipHostMalloc((void **)&sl.h_pm, sizeof(vh_p_match) * (size_t)S * cap_ps, hipHostMallocDefault));
+      sl.cap_ps = cap_ps;
+    }
+    if (!sl.h_cnt) VH_HIP(hipHostMalloc((void **)&sl.h_cnt, sizeof(int32_t) * 2 * (size_t)S, hipHostMallocDefault));
+    if (!sl.ev) VH_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    VH_HIP(hipStreamWaitEvent(down_stream, ev_post[last_buf], 0));
+    sl.width = cap_ps;
+    VH_HIP(hipMemcpy2DAsync(sl.h_pm, sizeof(vh_p_match) * (size_t)sl.cap_ps, d_matches, sizeof(vh_p_match) * (size_t)mcap,
+                            sizeof(vh_p_match) * (size_t)cap_ps, (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipMemcpyAsync(sl.h_cnt, d_match_count, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipMemcpyAsync(sl.h_cnt + S, d_overflow, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipEventRecord(sl.ev, down_stream));
+    // the next step's emission must not overwrite the lists before they have left (as vh_group_download_matches_async)
+    VH_HIP(hipEventRecord(ev_down, down_stream)); ev_down_valid = true;
+    sl.pending = true; sl.method = last_method;
+    post_seq++;
+    return VH_OK;
+  }
+
+  int32_t post_finish(int32_t age, int32_t max_features, float bw, float bh, int32_t threads, const vh_ego_params *e, const int32_t *rand3,
+                      double *tr, int32_t *ok, int32_t *ninl, vh_p_match *out, int32_t out_cap, int32_t *out_counts, double *host_ms) {
+    if (age < 0 || age > 1 || max_features < 1 || !(bw > 0) || !(bh > 0) || threads < 1) return VH_ERR_INVALID_ARG;
+    if (e && (!rand3 || !tr || !ok || !ninl || e->ransac_iters < 1)) return VH_ERR_INVALID_ARG;
+    if (post_seq - 1 - age < 0) return VH_ERR_STATE;
+    PostSlot &sl = post_slot[(post_seq - 1 - age) & 1];
+    if (!sl.pending) return VH_ERR_STATE;
+    VH_HIP(hipEventSynchronize(sl.ev));
+    sl.pending = false;
+    for (int32_t s = 0; s < S; s++)
+      if (sl.h_cnt[s] > sl.width || sl.h_cnt[S + s]) return VH_ERR_CAPACITY;  // a list longer than what was downloaded / a truncated feature set
+    // bucket grid bound: floor(u_max / bw) + 1 columns, floor(v_max / bh) + 1 rows (matcher.cpp:150-151)
+    const int64_t cols = (int64_t)floorf((float)(dims[0] - 1) / bw) + 1, rows = (int64_t)floorf((float)(dims[1] - 1) / bh) + 1;
+    const int64_t need = std::min<int64_t>(cols * rows * max_features, mcap);
+    if (bcap < need) {
+      if (h_bucket) { VH_HIP(hipHostFree(h_bucket)); h_bucket = nullptr; }
+      VH_HIP(hipHostMalloc((void **)&h_bucket, sizeof(vh_p_match) * (size_t)S * need, hipHostMallocDefault));
+      if (!h_bcnt) VH_HIP(hipHostMalloc((void **)&h_bcnt, sizeof(int32_t) * (size_t)S, hipHostMallocDefault));
+      int32_t rc;
+      if ((rc = dmalloc((uint8_t **)&d_bucket, sizeof(vh_p_match) * (size_t)S * need, false))) return rc;
+      if (!d_bcnt && (rc = dmalloc(&d_bcnt, (size_t)S, false))) return rc;
+      if ((rc = dmalloc(&d_post_xyz, (size_t)S * need * 4, false))) return rc;
+      if (!d_post_tr) { if ((rc = dmalloc(&d_post_tr, 6 * (size_t)S, false))) return rc; if ((rc = dmalloc(&d_post_ok, 2 * (size_t)S, false))) return rc; }
+      bcap = (int32_t)need;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::atomic<int32_t> next_stream(0), failed(0);
+    const bool vote = sl.method != VH_METHOD_STEREO;  // stereo records carry no previous-frame position (as remove_outliers())
+    const auto work = [&]() {
+      std::vector<int32_t> scratch;
+      for (int32_t s = next_stream++; s < S; s = next_stream++) {
+        vh_p_match *pm = sl.h_pm + (size_t)s * sl.cap_ps;
+        int32_t n = sl.h_cnt[s];
+        if (vote && vh_remove_outliers_pm(pm, n, &n) != VH_OK) { failed = 1; continue; }
+        h_bcnt[s] = bucket_records(pm, n, max_features, bw, bh, h_bucket + (size_t)s * bcap, bcap, scratch);
+      }
+    };
+    {
+      const int32_t nw = std::max(1, std::min(threads, S));
+      std::vector<std::thread> pool;
+      for (int32_t w = 1; w < nw; w++) pool.emplace_back(work);
+      work();
+      for (auto &t : pool) t.join();
+    }
+    if (host_ms) *host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (failed) return VH_ERR_INVALID_ARG;
+    for (int32_t s = 0; s < S; s++) if (h_bcnt[s] > bcap) return VH_ERR_CAPACITY;
+    if (out_counts) for (int32_t s = 0; s < S; s++) out_counts[s] = h_bcnt[s];
+    if (out) {
+      for (int32_t s = 0; s < S; s++) {
+        if (h_bcnt[s] > out_cap) return VH_ERR_CAPACITY;
+        memcpy(out + (size_t)s * out_cap, h_bucket + (size_t)s * bcap, sizeof(vh_p_match) * (size_t)h_bcnt[s]);
+      }
+    }
+    if (!e) return VH_OK;
+    if (sl.method != VH_METHOD_QUAD) return VH_ERR_STATE;  // the stereo estimator needs both cameras of both frames
+    const size_t nr = (size_t)S * e->ransac_iters * 3;
+    if (post_rand_n < nr) { int32_t rc = dmalloc(&d_post_rand, nr, false); if (rc) return rc; post_rand_n = nr; }
+    // the bucketed lists go up as one block; everything on the download stream, beside the next step's kernels
+    VH_HIP(hipMemcpyAsync(d_bucket, h_bucket, sizeof(vh_p_match) * (size_t)S * bcap, hipMemcpyHostToDevice, down_stream));
+    VH_HIP(hipMemcpyAsync(d_bcnt, h_bcnt, sizeof(int32_t) * (size_t)S, hipMemcpyHostToDevice, down_stream));
+    VH_HIP(hipMemcpyAsync(d_post_rand, rand3, sizeof(int32_t) * nr, hipMemcpyHostToDevice, down_stream));
+    vh_launch_ego(*e, S, d_bucket, bcap, nullptr, d_bcnt, bcap, d_post_rand, d_post_xyz, bcap, d_post_tr, d_post_ok, d_post_ok + S, nullptr, 0, down_stream);
+    VH_HIP(hipGetLastError());
+    VH_HIP(hipMemcpyAsync(tr, d_post_tr, sizeof(double) * 6 * (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipMemcpyAsync(ok, d_post_ok, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipMemcpyAsync(ninl, d_post_ok + S, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
+    VH_HIP(hipStreamSynchronize(down_stream));
+    static const bool timing = [] { const char *ev_ = getenv("VH_POST_TIMING"); return ev_ && ev_[0] == '1'; }();
+    if (timing) fprintf(stderr, "post_finish: host %.2f ms, upload + ego + results %.2f ms\n",
+                        host_ms ? *host_ms : -1.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - (host_ms ? *host_ms : 0.0));
+    return VH_OK;
+  }
+
   // Load caller-supplied feature records into a role's set and index it.
   int32_t load_features(int32_t role, const int32_t *m, int32_t n) {
     if (n < 0 || (n > 0 && !m)) return VH_ERR_INVALID_ARG;
@@ -844,6 +982,36 @@ void bucket_host(std::vector<vh_p_match> &pm, int32_t max_features, float bw, fl
     }
     for (int32_t j = 0, k = 0; j < len; j++) { pm.push_back(b[j]); if (++k >= max_features) break; }
   }
+}
+
+int32_t bucket_records(const vh_p_match *pm, int32_t n, int32_t max_features, float bw, float bh, vh_p_match *out, int32_t out_cap,
+                       std::vector<int32_t> &work) {
+  float u_max = 0, v_max = 0;
+  for (int32_t i = 0; i < n; i++) { if (pm[i].u1c > u_max) u_max = pm[i].u1c; if (pm[i].v1c > v_max) v_max = pm[i].v1c; }
+  const int32_t cols = (int32_t)floorf(u_max / bw) + 1, rows = (int32_t)floorf(v_max / bh) + 1, nb = cols * rows;
+  // counting sort of the record indices by bucket (row-major), stable: the reference appends in list order
+  work.assign((size_t)nb + 1 + (size_t)n, 0);
+  int32_t *start = work.data(), *idx = work.data() + nb + 1;
+  const auto bucket_of = [&](const vh_p_match &m) { return (int32_t)floorf(m.v1c / bh) * cols + (int32_t)floorf(m.u1c / bw); };
+  for (int32_t i = 0; i < n; i++) start[bucket_of(pm[i]) + 1]++;
+  for (int32_t b = 0; b < nb; b++) start[b + 1] += start[b];
+  {
+    std::vector<int32_t> cur(start, start + nb);
+    for (int32_t i = 0; i < n; i++) idx[cur[bucket_of(pm[i])]++] = i;
+  }
+  uint32_t rnd = 5;
+  int32_t kept = 0;
+  for (int32_t b = 0; b < nb; b++) {
+    int32_t *v = idx + start[b];
+    const int32_t len = start[b + 1] - start[b];
+    for (int32_t i = 1; i < len; i++) {  // random_shuffle, matcher.cpp:126-138
+      const int32_t j = (int32_t)(rnd % (uint32_t)(i + 1));
+      rnd = lfsr_next(rnd);
+      std::swap(v[i], v[j]);
+    }
+    for (int32_t j = 0, k = 0; j < len; j++) { if (kept < out_cap) out[kept] = pm[v[j]]; kept++; if (++k >= max_features) break; }
+  }
+  return kept;
 }
 
 int32_t check_params(const vh_params *p) {
@@ -1206,6 +1374,18 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
   (void)hipFree(d);
   if (er != hipSuccess) { t_last_error = hipGetErrorString(er); return VH_ERR_HIP; }
   return VH_OK;
+}
+
+int32_t vh_group_post_begin(vh_group *g, int32_t cap_per_stream) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->post_begin(cap_per_stream);
+}
+int32_t vh_group_post_finish(vh_group *g, int32_t age, int32_t max_features, float bucket_width, float bucket_height, int32_t host_threads,
+                             const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok, int32_t *n_inliers,
+                             vh_p_match *bucketed, int32_t cap_per_stream, int32_t *counts, double *host_ms) {
+  Group *gq = (Group *)g; ENTER(gq);
+  if (host_threads < 1) host_threads = (int32_t)std::max(1u, std::thread::hardware_concurrency());
+  return gq->post_finish(age, max_features, bucket_width, bucket_height, host_threads, e, rand3, tr, ok, n_inliers, bucketed, cap_per_stream, counts, host_ms);
 }
 
 // ---- monocular egomotion -----------------------------------------

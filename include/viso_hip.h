@@ -313,6 +313,29 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
 int32_t vh_group_estimate_motion(vh_group *g, const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok,
                                  int32_t *n_inliers);
 
+/* ---- the steps after matching, pipelined ------------------------------------------------------------- */
+/* What the reference's loop runs between Matcher::matching and the pose -- removeOutliers (the tail of
+ * matchFeatures, src/matcher.cpp:108), bucketFeatures (src/viso_stereo.cpp:41-43 -> src/matcher.cpp:140-187)
+ * and VisualOdometryStereo::estimateMotion (src/viso_stereo.cpp:49-51) -- for every stream of a group,
+ * arranged so that the host part of step t runs beside the GPU work of step t+1:
+ *   vh_group_post_begin   after vh_group_match_features: starts the download of the step's match lists (the
+ *                         first cap_per_stream records of every stream) into one of two internal page-locked
+ *                         slots and returns at once.
+ *   vh_group_post_finish  age 0: the step begun last, 1: the one before.  Waits for that download, runs the
+ *                         Delaunay vote (flow and quad lists) and the bucketing of every stream on host_threads
+ *                         host threads (<= 0: one per hardware thread), copies the bucketed lists to
+ *                         bucketed[s * cap_per_stream ..] / counts[s] (either may be NULL), and -- if e != NULL
+ *                         (quad lists only) -- uploads them (a few hundred records per stream) and runs the
+ *                         batched egomotion kernel: tr[S][6], ok[S], n_inliers[S] as vh_group_estimate_motion,
+ *                         rand3[S][ransac_iters][3].  *host_ms (nullable) = wall time of the host part.
+ * VH_ERR_CAPACITY when a list was longer than the slot or a feature set was truncated.  The lists
+ * vh_group_get_matches returns are not changed by these calls. */
+int32_t vh_group_post_begin(vh_group *g, int32_t cap_per_stream);
+int32_t vh_group_post_finish(vh_group *g, int32_t age, int32_t max_features, float bucket_width, float bucket_height,
+                             int32_t host_threads, const vh_ego_params *e, const int32_t *rand3, double *tr, int32_t *ok,
+                             int32_t *n_inliers, vh_p_match *bucketed, int32_t cap_per_stream, int32_t *counts,
+                             double *host_ms);
+
 /* ---- monocular egomotion (mono half) ---------------------------- */
 
 /* VisualOdometryMono::parameters and the calibration it reads (src/viso_mono.h:32-46, src/viso.h:41-50). */

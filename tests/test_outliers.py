@@ -259,3 +259,57 @@ def test_group_remove_outliers_equals_per_stream(pkg, ob, oracle, gpu):
     g.matchFeatures(pkg.METHOD_QUAD)
     assert all(len(g.getMatches(s)) > 0 for s in range(S))
     g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_pipelined_post_stage_matches_the_oracle_chain(pkg, ob, oracle, gpu):
+    """vh_group_post_begin / vh_group_post_finish: removeOutliers -> bucketFeatures(2, 50, 50) -> stereo
+    estimateMotion of step t finished while step t+1 is already issued (age 1), per stream equal to the
+    oracle's chain on the same quad matches: bucketed lists bit for bit, inlier counts exact, tr to 1e-9."""
+    S, W, H, T = 3, 480, 200, 4
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, T, disparity=6 + s, blur=4, seed=400 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(T)] for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    ge = pkg.EgoParams.default(f=400.0, cu=W / 2, cv=H / 2, base=0.5)
+    e = ob.EgoParams.default(f=400.0, cu=W / 2, cv=H / 2, base=0.5)
+    raw = np.random.default_rng(3).integers(0, 2 ** 31 - 1, (T, S, 200, 3)).astype(np.int32)
+    import ctypes as C
+
+    def want(t):
+        res = []
+        for s in range(S):
+            pm = oracle.matching(po, dims, 2, F[s][t - 1][0], F[s][t - 1][1], F[s][t][0], F[s][t][1])
+            pm, _ = oracle.remove_outliers(pm)
+            q = pm.copy()
+            n = oracle.lib.vo_bucket_features(q.ctypes.data_as(C.c_void_p), len(q), 2, C.c_float(50), C.c_float(50))
+            q = q[:n].copy()
+            res.append((q, oracle.estimate_motion_stereo(e, q, oracle.draw_samples(len(q), 200, raw[t, s].reshape(-1)))))
+        return res
+
+    def check(t, got):
+        for s, (q, (ok_o, tr_o, inl_o)) in enumerate(want(t)):
+            assert len(q) > 20 and got["lists"][s].tobytes() == q.tobytes(), (t, s)
+            assert got["ok"][s] == ok_o and got["n_inliers"][s] == len(inl_o), (t, s)
+            assert np.allclose(got["tr"][s], tr_o, rtol=1e-9, atol=1e-12), (t, s, got["tr"][s], tr_o)
+
+    with pytest.raises(pkg.VisoHipError):
+        g.postFinish(0, 2, 50.0, 50.0)  # nothing begun
+    for t in range(T):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+        if t == 0:
+            continue
+        g.matchFeatures(pkg.METHOD_QUAD)
+        g.postBegin(8192)
+        if t >= 2:  # step t is in flight on the GPU; finish step t-1
+            check(t - 1, g.postFinish(1, 2, 50.0, 50.0, host_threads=2, ego=ge, rand3=raw[t - 1]))
+    check(T - 1, g.postFinish(0, 2, 50.0, 50.0, host_threads=2, ego=ge, rand3=raw[T - 1]))
+    # the device lists are untouched by the post stage
+    assert g.getMatches(0).tobytes() == oracle.matching(po, dims, 2, F[0][T - 2][0], F[0][T - 2][1], F[0][T - 1][0], F[0][T - 1][1]).tobytes()
+    # a slot shorter than a list is reported
+    g.postBegin(16)
+    with pytest.raises(pkg.VisoHipError) as ex:
+        g.postFinish(0, 2, 50.0, 50.0)
+    assert ex.value.code == pkg.VH_ERR_CAPACITY
+    g.close()
