@@ -457,18 +457,24 @@ detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_
         vn = min((int32_t)mn.x, (int32_t)mn.y);
         vx = max((int32_t)mx.x, (int32_t)mx.y);
       } else {
-        vn = b[0]; vx = vn;
+        // value and scan position in one key: min over (value << 6 | kk) is the smallest value at its FIRST
+        // position in scan order, max over (value << 6 | 63 - kk) the largest value at its first position --
+        // the reference's strict `<` / `else if >` updates (matcher.cpp:397-405; the `else` never matters:
+        // a value below the running minimum cannot exceed the running maximum).  Stored responses are
+        // f + 8192 in [0, 16383], kk = row << 3 | column <= 36.  One v_lshl_add per key and one
+        // v_min3 / v_max3 per two pixels instead of two compares and four selects per pixel.
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
         for (int32_t j = 0; j < N1; j++) {
 #pragma unroll
           for (int32_t i = 0; i < N1; i++) {
-            if (i == 0 && j == 0) continue;
-            const int32_t cur = b[j * T::FP + i], kk = (j << 3) | i;
-            const bool lt = cur < vn, gt = !lt && cur > vx;  // `else if`: first extremum wins (matcher.cpp:397-405)
-            vn = lt ? cur : vn; pn = lt ? kk : pn;
-            vx = gt ? cur : vx; px = gt ? kk : px;
+            const uint32_t cur = (uint32_t)(uint16_t)b[j * T::FP + i], kk = (uint32_t)((j << 3) | i);
+            kmin = min(kmin, (cur << 6) + kk);
+            kmax = max(kmax, (cur << 6) + (63u - kk));
           }
         }
+        vn = (int32_t)(kmin >> 6); pn = (int32_t)(kmin & 63u);
+        vx = (int32_t)(kmax >> 6); px = 63 - (int32_t)(kmax & 63u);
       }
 #pragma unroll
       for (int32_t mm = 0; mm < 2; mm++) {  // 0: the block minimum, 1: the block maximum
