@@ -31,6 +31,9 @@
 namespace {
 
 #define MONO_T 256
+#ifndef MONO_LDS_ROWS
+#define MONO_LDS_ROWS 640  // 45 KB: inlier sets of bucketed lists (a few hundred) fit; longer ones take the global-memory path
+#endif
 
 __device__ __forceinline__ double sign_of(double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); }
 
@@ -623,6 +626,10 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
                   int64_t cap, double *__restrict__ tr_out, int32_t *__restrict__ ok_out, int32_t *__restrict__ ninl_out,
                   int32_t *__restrict__ inl_out, int64_t inl_stride) {
   __shared__ double sF[9], sV[81], sX[16], sM[48];  // sM: R candidates Ra[9], Rb[9], t0[3], P1/P2 rows ...
+  // The refit system lives in LDS when it fits (MONO_LDS_ROWS x 9 doubles): the cooperative SVD's sequential sums
+  // are chains of dependent accumulations over a column, one load per step -- from global memory each step waited
+  // out an L2 round trip (7.8 of the 15 ms a 256 x 400 x 2000 batch took), from LDS a few dozen cycles.
+  __shared__ double sA[MONO_LDS_ROWS * 9];
   __shared__ double sP[4][12];                      // P2 of the four (R, t) candidates
   __shared__ double sK[12];                         // P1 = [K | 0]
   __shared__ int32_t sNeg[9], sWave[MONO_T / 64], sBase, sCnt[4], sFlag;
@@ -672,16 +679,17 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
   }
   if (nbest < 10) { fail(nbest); return; }  // src/viso_mono.cpp:80-81
   // F from all inliers: the nbest x 9 system (src/viso_mono.cpp:84, :242-256)
+  double *Asys = nbest <= MONO_LDS_ROWS ? sA : L.A;
   for (int32_t i = tid; i < nbest; i += MONO_T) {
     const float4 q = L.pn[L.idx[i]];
-    double *r = L.A + (int64_t)i * 9;
+    double *r = Asys + (int64_t)i * 9;
     r[0] = (double)(q.z * q.x); r[1] = (double)(q.z * q.y); r[2] = (double)q.z;
     r[3] = (double)(q.w * q.x); r[4] = (double)(q.w * q.y); r[5] = (double)q.w;
     r[6] = (double)q.x; r[7] = (double)q.y; r[8] = 1.0;
   }
   __syncthreads();
   double w9[9];
-  svd_tall9(L.A, nbest, sV, sX, sNeg, w9, L.d);
+  svd_tall9(Asys, nbest, sV, sX, sNeg, w9, L.d);
   if (tid == 0) {
     double F0[9], F[9], T1[9], T2[9], E[9], Kt[9];
     const double K[9] = {e.f, 0, e.cu, 0, e.f, e.cv, 0, 0, 1};

@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --no-cpu --no-exclusive > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --no-cpu --no-exclusive --no-e2e > $OUT/bench_stats.log 2>&1
 tail -1 $OUT/bench_stats.log | cut -c1-300
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --no-cpu --no-exclusive --steps 6 --warmup 2 > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --no-cpu --no-exclusive --steps 6 --warmup 2 > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py --no-cpu --no-exclusive --no-e2e --steps 6 --warmup 2 --blocks 1 > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py --no-cpu --no-exclusive --no-e2e --steps 6 --warmup 2 --blocks 1 > $OUT/bench_write.log 2>&1
 python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 tail -c 600 $OUT/bench_plain.json
