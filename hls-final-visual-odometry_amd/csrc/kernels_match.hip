@@ -8,22 +8,24 @@
 //    is a pure function of (query feature, candidate set), so here every pass
 //    of a chain is evaluated for ALL features of its query set at once
 //    (`match`), and the chains are then followed by table look-ups (`chain`).
-//  * Mapping: one LANE per QUERY, one wavefront per tile of <= 64 consecutive
-//    bin-ordered queries (of one class; of one (class, u-bin) column when the v
-//    window does not span the image).  The candidate stream is then wave-uniform:
-//    all 64 lanes walk the same bin range, candidates are staged 64 at a time in
-//    a wave-private LDS chunk and broadcast-read, and the SAD is 8 v_sad_u8 /
-//    v_sad_hi_u8 per lane and query with no cross-lane reduction at all.
-//    Positions in bin order ARE the reference's visiting order, so its
-//    first-minimum tie-break (strict `<`, src/matcher.cpp:264) is the minimum of
-//    the key (SAD << 19 | position) -- or (SAD << 16 | position - class base),
-//    which the v_sad_hi_u8 chain produces by itself -- whatever order
-//    candidates arrive in.
-//  * Each lane applies the reference's accept test on its own window
-//    (src/matcher.cpp:249); the wave only walks the union of its lanes' bin
-//    ranges (src/matcher.cpp:237-240), which never changes a lane's result
-//    because a candidate inside a lane's window always lies inside that lane's
-//    bin range.
+//  * Mapping (flow_tile / rows_tile below): one wavefront per tile of <= 32 consecutive
+//    bin-ordered queries of one class (row-ordered for the 1-d stereo passes).  The 64 lanes are
+//    4 phases of 16 lanes, lane (phase, l) holds queries l and l+16, so every phase holds the
+//    whole tile; the candidate region of the tile -- the union of its queries' bin ranges -- is
+//    streamed through a wave-private LDS chunk of 64 candidates, and the four phases take
+//    candidates j, j+1, j+2, j+3 of it in the same step: one candidate stream shared by all
+//    phases, every record read from LDS serves two queries per lane, 8 v_sad_u8 / v_sad_hi_u8 per
+//    pair, the partial minima joined by two shuffles per tile.
+//    Positions in bin order ARE the reference's visiting order, so its first-minimum tie-break
+//    (strict `<`, src/matcher.cpp:264) is the minimum of the key (SAD << 19 | position) -- or
+//    (SAD << 16 | position - class base), which the v_sad_hi_u8 chain produces by itself --
+//    whatever order candidates arrive in.
+//  * The accept test of src/matcher.cpp:249 is applied per pair only in the "tested" form of the
+//    loops.  The default, speculative form applies none: every lane takes the minimum over the
+//    whole region the wave walks, a superset of its own window, tests ONE candidate at the end --
+//    its winner -- and the few queries whose winner lies outside their own window are searched
+//    again exactly, in groups sharing one walk (finish_tile / RedoGroup).  Either way the result
+//    is findMatch's; engine.hip picks the form per launch from the observed share of such queries.
 #include "vh_dev.h"
 #include <algorithm>
 #include <cstdlib>
