@@ -74,7 +74,13 @@ struct Group {
   hipEvent_t ev_post[2] = {nullptr, nullptr};    // post-processing finished reading buffer b
   bool ev_post_valid[2] = {false, false};
   int64_t match_seq = 0;
-  int32_t *d_mchunk = nullptr;   // [S][cap/256] survivors per emission chunk, followed by the 2 statistics words of the launch
+  int32_t *d_mchunk2[2] = {nullptr, nullptr};  // [S][cap/256] survivors per emission chunk, one buffer per match-table buffer (each launch's emission zeroes the other one)
+  // per stream {match count, overflow flag, queries searched again, queries searched} of the last launch on each
+  // buffer, written by emit_matches into host-mapped page-locked memory: valid after ev_post[buf]
+  int4 *h_out[2] = {nullptr, nullptr}, *d_out_mapped[2] = {nullptr, nullptr};
+  // small groups (serial): the match records are written to host-mapped memory as well, so getMatches is an
+  // event wait and a host copy instead of a device->host transfer of its own
+  vh_p_match *h_matches = nullptr; void *d_matches_mapped = nullptr;
   int32_t *d_redo = nullptr;     // [2][S] queries the speculative searches had to search again, per table buffer (reset by emit_matches)
   // Loop policy of the searches (match()): speculative (no accept test in the loop, the winner
   // verified, failures searched again) or tested.  The speculative loop is ~12 % faster when
@@ -83,10 +89,8 @@ struct Group {
   // without a partner).  Every launch reports (re-searched, searched) with a lag of one or two
   // steps; above 3 % the tested loop takes over and the speculative one is probed every 16th
   // launch, below 2 % it comes back.  Results never depend on the choice.
-  int32_t *h_stats = nullptr;    // page-locked [2][2]
-  hipEvent_t ev_stats[2] = {nullptr, nullptr};
   bool stats_pending[2] = {false, false}, stats_was_spec[2] = {false, false};
-  int32_t stats_slot = 0, probe_countdown = 0, force_mode = -1;
+  int32_t probe_countdown = 0, force_mode = -1;
   bool spec_mode = true;
   double last_redo_rate = -1;
   hipEvent_t ev_det[VH_RING] = {};   // slot fully detected + indexed
@@ -116,6 +120,7 @@ struct Group {
   bool ev_stage_valid[2] = {false, false};
   int32_t stage_slot = 0;
   hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_h2d = nullptr;
   size_t stage_bytes = 0;
   // asynchronous download of the match lists (vh_group_download_matches_async)
   hipStream_t down_stream = nullptr;
@@ -150,11 +155,11 @@ struct Group {
     if (ev_user) (void)hipEventDestroy(ev_user);
     for (int k = 0; k < 2; k++) if (ev_stage[k]) (void)hipEventDestroy(ev_stage[k]);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (ev_h2d) (void)hipEventDestroy(ev_h2d);
     if (ev_down) (void)hipEventDestroy(ev_down);
     for (auto &sl : post_slot) if (sl.ev) (void)hipEventDestroy(sl.ev);
     if (down_stream) (void)hipStreamDestroy(down_stream);
-    for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); if (ev_stats[k]) (void)hipEventDestroy(ev_stats[k]); }
-    if (h_stats) (void)hipHostFree(h_stats);
+    for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); }
     if (post_stream && own_post) (void)hipStreamDestroy(post_stream);
     if (match_stream && !serial) (void)hipStreamDestroy(match_stream);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -193,7 +198,9 @@ struct Group {
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0; ev_down_valid = false;
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
     d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
-    d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk = nullptr; d_redo = nullptr;
+    d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk2[0] = d_mchunk2[1] = nullptr; d_redo = nullptr;
+    for (int k = 0; k < 2; k++) if (h_out[k]) { (void)hipHostFree(h_out[k]); h_out[k] = nullptr; d_out_mapped[k] = nullptr; }
+    if (h_matches) { (void)hipHostFree(h_matches); h_matches = nullptr; d_matches_mapped = nullptr; }
     stats_pending[0] = stats_pending[1] = false;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
     d_ego_rand = nullptr; d_ego_ok = nullptr; d_ego_xyz = nullptr; d_ego_tr = nullptr; ego_rand_n = 0;
@@ -319,10 +326,19 @@ struct Group {
       if ((rc = dmalloc(&d_chain2[k], 2 * (size_t)S * cap, false))) return rc;  // index tuple + coordinate tuple per driving feature
     }
     d_best = d_best2[0]; d_chain = d_chain2[0];
-    if ((rc = dmalloc(&d_mchunk, (size_t)S * ((cap + 255) / 256) + 2, true))) return rc;
+    for (int k = 0; k < 2; k++) {
+      if ((rc = dmalloc(&d_mchunk2[k], (size_t)S * ((cap + 255) / 256), true))) return rc;
+      VH_HIP(hipHostMalloc((void **)&h_out[k], sizeof(int4) * (size_t)S, hipHostMallocMapped));
+      memset(h_out[k], 0, sizeof(int4) * (size_t)S);
+      VH_HIP(hipHostGetDevicePointer((void **)&d_out_mapped[k], h_out[k], 0));
+    }
     if ((rc = dmalloc(&d_redo, 2 * (size_t)S, true))) return rc;  // one set of counters per match-table buffer: the search of match n+1 runs beside the emission of match n
     if ((rc = dmalloc((uint8_t **)&d_matches, (size_t)S * mcap * sizeof(vh_p_match), false))) return rc;
     if ((rc = dmalloc(&d_match_count, (size_t)S, true))) return rc;
+    if (serial && (size_t)S * mcap * sizeof(vh_p_match) <= (64u << 20)) {
+      VH_HIP(hipHostMalloc((void **)&h_matches, (size_t)S * mcap * sizeof(vh_p_match), hipHostMallocMapped));
+      VH_HIP(hipHostGetDevicePointer(&d_matches_mapped, h_matches, 0));
+    }
     if ((rc = dmalloc(&d_overflow, (size_t)S, true))) return rc;
     VH_HIP(hipHostMalloc((void **)&h_overflow, sizeof(int32_t) * (size_t)S, hipHostMallocDefault));
     memset(h_overflow, 0, sizeof(int32_t) * (size_t)S);
@@ -466,22 +482,27 @@ struct Group {
     const int32_t sl = stage_slot;
     stage_slot ^= 1;
     // the detection that last read this staging slot (two pushes ago) must be done
-    if (ev_stage_valid[sl]) VH_HIP(hipStreamWaitEvent(copy_stream, ev_stage[sl], 0));
+    hipStream_t cs = serial ? stream : copy_stream;  // (a small group runs everything on one stream: no hand-over between streams)
+    if (ev_stage_valid[sl] && !serial) VH_HIP(hipStreamWaitEvent(cs, ev_stage[sl], 0));
     for (int k = 0; k < 2; k++) {
       const uint8_t *src = k ? I2 : I1;
       d_stage[k] = d_stage_buf[sl][k];
       if (!src) continue;
       if (stride == (int64_t)isz) {  // one transfer for all S images
-        VH_HIP(hipMemcpyAsync(d_stage[k], src, isz * S, hipMemcpyHostToDevice, copy_stream));
+        VH_HIP(hipMemcpyAsync(d_stage[k], src, isz * S, hipMemcpyHostToDevice, cs));
       } else {
         for (int32_t s = 0; s < S; s++)
-          VH_HIP(hipMemcpyAsync(d_stage[k] + isz * s, src + stride * s, isz, hipMemcpyHostToDevice, copy_stream));
+          VH_HIP(hipMemcpyAsync(d_stage[k] + isz * s, src + stride * s, isz, hipMemcpyHostToDevice, cs));
       }
     }
-    // the images are only borrowed for the duration of the call (demo.cpp:250-251);
-    // the copy runs beside the previous step's kernels, the host waits for it here
-    VH_HIP(hipStreamSynchronize(copy_stream));
+    // The images are only borrowed for the duration of the call (demo.cpp:250-251): the host waits for the
+    // copies -- but only after the detection has been queued behind them, so the first kernel starts
+    // when the last byte lands instead of a host round trip later.
+    if (!ev_h2d) VH_HIP(hipEventCreateWithFlags(&ev_h2d, hipEventDisableTiming));
+    VH_HIP(hipEventRecord(ev_h2d, cs));
+    if (!serial) VH_HIP(hipStreamWaitEvent(stream, ev_h2d, 0));
     rc = push_device(d_stage[0], I2 ? d_stage[1] : nullptr, (int64_t)isz, d, replace);
+    VH_HIP(hipEventSynchronize(ev_h2d));
     if (rc == VH_OK) {
       VH_HIP(hipEventRecord(ev_stage[sl], stream));
       ev_stage_valid[sl] = true;
@@ -509,10 +530,12 @@ struct Group {
   bool choose_loop() {
     if (force_mode >= 0) return force_mode == 1;
     for (int sl = 0; sl < 2; sl++) {
-      if (!stats_pending[sl] || hipEventQuery(ev_stats[sl]) != hipSuccess) continue;
+      if (!stats_pending[sl] || hipEventQuery(ev_post[sl]) != hipSuccess) continue;
       stats_pending[sl] = false;
-      if (!stats_was_spec[sl] || h_stats[2 * sl + 1] <= 0) continue;  // the tested loop reports nothing
-      last_redo_rate = (double)h_stats[2 * sl] / (double)h_stats[2 * sl + 1];
+      int64_t again = 0, searched = 0;
+      for (int32_t s = 0; s < S; s++) { again += h_out[sl][s].z; searched += h_out[sl][s].w; }
+      if (!stats_was_spec[sl] || searched <= 0) continue;  // the tested loop reports nothing
+      last_redo_rate = (double)again / (double)searched;
       if (spec_mode && last_redo_rate > 0.03) { spec_mode = false; probe_countdown = 16; }
       else if (!spec_mode && last_redo_rate < 0.02) spec_mode = true;
     }
@@ -538,8 +561,7 @@ struct Group {
     VH_HIP(hipGetLastError());
     VH_HIP(hipEventRecord(ev_tables[buf], ms));
     VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
-    const size_t n_mchunk = (size_t)S * ((cap + 255) / 256);
-    VH_HIP(hipMemsetAsync(d_mchunk, 0, sizeof(int32_t) * (n_mchunk + 2), ps));  // chunk counters + the launch's two statistics words
+    int32_t *d_mchunk = d_mchunk2[buf];  // zeroed by the previous launch's emission (at allocation for the first two)
     if (method == VH_METHOD_FLOW) {
       if (!d_mask) {
         int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) return rc;
@@ -554,14 +576,10 @@ struct Group {
     { Scope sc(this, "chain", ps); vh_launch_chain(sets, a, method, d_best2[buf], d_chain2[buf], d_mask, epoch, d_mchunk, ps); }
     // a download of the previous step's lists may still be reading d_matches
     if (ev_down_valid) VH_HIP(hipStreamWaitEvent(ps, ev_down, 0));
-    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, d_redo + (size_t)buf * S, d_mchunk + n_mchunk, ps); }
+    { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, d_redo + (size_t)buf * S, d_mchunk2[buf ^ 1], d_out_mapped[buf], d_matches_mapped, ps); }
     VH_HIP(hipGetLastError());
-    {  // (re-searched, searched) of this launch -> page-locked memory, read by a later choose_loop()
-      const int32_t sl = stats_slot; stats_slot ^= 1;
-      VH_HIP(hipMemcpyAsync(h_stats + 2 * sl, d_mchunk + n_mchunk, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ps));
-      VH_HIP(hipEventRecord(ev_stats[sl], ps));
-      stats_pending[sl] = true; stats_was_spec[sl] = spec;
-    }
+    // (re-searched, searched) of this launch are read from h_out[buf] by a later choose_loop()
+    stats_pending[buf] = true; stats_was_spec[buf] = spec;
     VH_HIP(hipEventRecord(ev_post[buf], ps)); ev_post_valid[buf] = true;
     // both slots stay in use until this point of the post stream
     VH_HIP(hipEventRecord(ev_read[pair_cur], ps)); ev_read_valid[pair_cur] = true;
@@ -605,14 +623,15 @@ struct Group {
       if (k) memcpy(out, host_matches[s].data(), sizeof(vh_p_match) * (size_t)k);
       return *n > capo ? VH_ERR_CAPACITY : VH_OK;
     }
-    int32_t cnt = 0, ov = 0;
-    VH_HIP(hipMemcpyAsync(&cnt, d_match_count + s, sizeof(int32_t), hipMemcpyDeviceToHost, post_stream));
-    VH_HIP(hipMemcpyAsync(&ov, d_overflow + s, sizeof(int32_t), hipMemcpyDeviceToHost, post_stream));
-    VH_HIP(hipStreamSynchronize(post_stream));
+    // count and overflow flag of the last launch: host-mapped memory, valid once its emission has run
+    VH_HIP(hipEventSynchronize(ev_post[last_buf]));
     { const int32_t rv_ = check_violation(); if (rv_) return rv_; }
+    const int32_t cnt = h_out[last_buf][s].x, ov = h_out[last_buf][s].y;
     *n = cnt;
     const int32_t k = std::min(std::min(cnt, mcap), capo);
-    if (k > 0) {
+    if (k > 0 && h_matches) {
+      memcpy(out, h_matches + (size_t)s * mcap, sizeof(vh_p_match) * (size_t)k);
+    } else if (k > 0) {
       VH_HIP(hipMemcpyAsync(out, (const uint8_t *)d_matches + (size_t)s * mcap * sizeof(vh_p_match),
                             sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost, post_stream));
       VH_HIP(hipStreamSynchronize(post_stream));
@@ -1053,9 +1072,12 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
   gq->stream = gq->own_stream;
   // VH_SERIAL=1 (profiling aid): run matching on the detect stream, i.e. no
   // overlap, so that per-kernel timings are exclusive
+  // A small group (one or two cameras: the drop-in Matcher) also runs on one stream: it fills a few percent of
+  // the chip, detection of frame t+1 has nothing to hide behind, and every hand-over between streams is a
+  // ~14 us bubble on the path pushBack -> matchFeatures -> getMatches (VH_SERIAL=0 keeps the three streams).
   const char *serial = getenv("VH_SERIAL");
   bool ok = true;
-  if (serial && serial[0] == '1') gq->match_stream = gq->post_stream = gq->own_stream, gq->serial = true;
+  if (serial ? serial[0] == '1' : S <= 2) gq->match_stream = gq->post_stream = gq->own_stream, gq->serial = true;
   else {
     ok = hipStreamCreateWithPriority(&gq->match_stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
     // The chain/emission step runs on a stream of its own so that consecutive searches run back
@@ -1073,9 +1095,6 @@ int32_t group_new(const vh_params *p, int32_t device, int32_t S, int32_t mf, int
     ok = hipEventCreateWithFlags(&gq->ev_det[k], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&gq->ev_read[k], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&gq->ev_user, hipEventDisableTiming) == hipSuccess;
-  for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&gq->ev_stats[k], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipHostMalloc((void **)&gq->h_stats, 4 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
-  if (ok) memset(gq->h_stats, 0, 4 * sizeof(int32_t));
   // VH_FLOW_TESTED=1 / =0: always the tested / always the speculative loops (default: adaptive)
   if (const char *ft = getenv("VH_FLOW_TESTED")) gq->force_mode = atoi(ft) ? 0 : 1;
   for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&gq->ev_stage[k], hipEventDisableTiming) == hipSuccess;

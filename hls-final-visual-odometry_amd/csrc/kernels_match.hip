@@ -909,10 +909,14 @@ __global__ void __launch_bounds__(256)
 emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restrict__ chain,
                     float *__restrict__ matches, int32_t mcap, int32_t *__restrict__ match_count,
                     int32_t *__restrict__ overflow, const int32_t *__restrict__ mchunk, int32_t nchm,
-                    int32_t *__restrict__ redo, int32_t *__restrict__ stats) {
+                    int32_t *__restrict__ redo, int32_t *__restrict__ mchunk_next, int4 *__restrict__ host_out,
+                    float *__restrict__ host_matches) {
   __shared__ int32_t sWave[4];
   __shared__ int32_t sBase;
   const int32_t chunk = blockIdx.x, stream = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // the chunk counters of the NEXT launch (the other buffer; its last reader, the emission before this one, is done)
+  // are zeroed here instead of by a memset of their own: two fill kernels and a launch gap per step
+  if (tid == 0) mchunk_next[stream * nchm + chunk] = 0;
   int32_t sets[4];
 #pragma unroll
   for (int32_t r = 0; r < 4; r++) sets[r] = vh_role_set(a.S, a.pair_cur, stream, r);
@@ -965,6 +969,10 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
     o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
     o[2] = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+    if (host_matches) {  // small groups: the records also go straight to host-mapped memory (no download before getMatches)
+      uint4 *h = (uint4 *)(host_matches + ((int64_t)stream * mcap + pos) * 12);
+      h[0] = o[0]; h[1] = o[1]; h[2] = o[2];
+    }
   }
   if (chunk == nchm - 1 && tid == 0) {
     match_count[stream] = base + tot;
@@ -981,8 +989,9 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
     int32_t nq = 0;
 #pragma unroll
     for (int32_t k = 0; k < 4; k++) if (k < a.npass) nq += min(s.count[vh_role_set(a.S, a.pair_cur, stream, a.pass[k].qset)], s.cap);
-    atomicAdd(&stats[0], redo[stream]);
-    atomicAdd(&stats[1], nq);
+    // count, overflow flag and the launch's statistics also go straight to host-mapped memory: the host reads
+    // them after the launch's event instead of through small device->host copies (each a blit kernel + a round trip)
+    host_out[stream] = make_int4(base + tot, ov, redo[stream], nq);
     redo[stream] = 0;
   }
 }
@@ -1025,8 +1034,9 @@ void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, cons
 }
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
                             void *matches, int32_t mcap, int32_t *match_count, int32_t *overflow,
-                            const int32_t *mchunk, int32_t *redo, int32_t *stats, hipStream_t st) {
+                            const int32_t *mchunk, int32_t *redo, int32_t *mchunk_next, void *host_out, void *host_matches,
+                            hipStream_t st) {
   const int32_t nchm = (s.cap + 255) / 256;
   hipLaunchKernelGGL(emit_matches_kernel, dim3(nchm, a.S), dim3(256), 0, st, s, a, method, chain,
-                     (float *)matches, mcap, match_count, overflow, mchunk, nchm, redo, stats);
+                     (float *)matches, mcap, match_count, overflow, mchunk, nchm, redo, mchunk_next, (int4 *)host_out, (float *)host_matches);
 }

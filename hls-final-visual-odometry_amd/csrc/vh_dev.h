@@ -188,7 +188,8 @@ void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, cons
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st);
 void vh_launch_emit_matches(const VhSets &s, const VhMatchArgs &a, int32_t method, const int4 *chain,
                             void *matches, int32_t mcap, int32_t *match_count, int32_t *overflow,
-                            const int32_t *mchunk, int32_t *redo, int32_t *stats, hipStream_t st);
+                            const int32_t *mchunk, int32_t *redo, int32_t *mchunk_next, void *host_out, void *host_matches,
+                            hipStream_t st);
 
 struct vh_ego_params;
 struct vh_p_match;
