@@ -27,6 +27,8 @@
 #include "vh_dev.h"
 #include "../../include/viso_hip.h"
 #include <math.h>
+#define SVD_HD __device__ __forceinline__
+#include "svd_static.h"
 
 namespace {
 
@@ -261,14 +263,21 @@ __device__ void matmul(const double *A, int ma, int na, const double *B, int nb,
 __device__ void transpose3(const double *A, double *T) {
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[j * 3 + i] = A[i * 3 + j];
 }
-// Matrix::svd of a 3x3 followed by U * diag(W with W[2] = 0) * ~V (src/viso_mono.cpp:262-265, :91-94)
+// Matrix::svd of a 3x3 followed by U * diag(W with W[2] = 0) * ~V (src/viso_mono.cpp:262-265, :91-94).
+// The factors live in registers (svd_static.h: every index static after unrolling).
 __device__ void rank2_3x3(const double *M, double *out) {
-  double a[9], w[3], v[9], tmp[9], D[9], UD[9], Vt[9];
-  for (int i = 0; i < 9; i++) { a[i] = M[i]; D[i] = 0.0; }
-  svd_lane(a, 3, 3, w, v, tmp);
+  double U[3][3], w[3], V[3][3], a[9], D[9], UD[9], Vt[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) U[i][j] = M[i * 3 + j];
+  svd_static<3, 3>(U, w, V);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { a[i * 3 + j] = U[i][j]; Vt[j * 3 + i] = V[i][j]; D[i * 3 + j] = 0.0; }
   D[0] = w[0]; D[4] = w[1]; D[8] = 0.0;
   matmul(a, 3, 3, D, 3, UD);
-  transpose3(v, Vt);
   matmul(UD, 3, 3, Vt, 3, out);
 }
 
@@ -410,8 +419,24 @@ __device__ void fundamental8(const float4 *pn, const int32_t *act, double *F) {
     r[3] = (double)(q.w * q.x); r[4] = (double)(q.w * q.y); r[5] = (double)q.w;
     r[6] = (double)q.x; r[7] = (double)q.y; r[8] = 1.0;
   }
+#ifndef VH_MONO_SCRATCH89
+  // In registers (svd_static.h; U entirely, V partly -- the compiler keeps 92 of V's doubles in private memory at
+  // 366 registers): 256 x 400 x 2000 batches 12.6 -> 8.9 ms against the private-memory form below (-DVH_MONO_SCRATCH89).
+  {
+    double Ur[8][9], wr[9], Vr[9][9], lv[9];
+#pragma unroll
+    for (int32_t i = 0; i < 8; i++)
+#pragma unroll
+      for (int32_t q = 0; q < 9; q++) Ur[i][q] = a[i * 9 + q];
+    svd_static_last_v<8, 9>(Ur, wr, Vr, lv);
+#pragma unroll
+    for (int32_t i = 0; i < 9; i++) F0[i] = lv[i];
+    (void)w; (void)v; (void)tmp;
+  }
+#else
   svd_lane(a, 8, 9, w, v, tmp);
   for (int32_t i = 0; i < 9; i++) F0[i] = v[i * 9 + 8];
+#endif
   rank2_3x3(F0, F);
 }
 
@@ -702,9 +727,19 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
     for (int32_t q = 0; q < 9; q++) E[q] = T1[q];
     // EtoRt (src/viso_mono.cpp:317-346)
     const double Wm[9] = {0, -1, 0, +1, 0, 0, 0, 0, 1}, Zm[9] = {0, +1, 0, -1, 0, 0, 0, 0, 0};
-    double U[9], S[3], V[9], tmp[9], Ut[9], Vt[9], Wt[9], T[9];
-    for (int32_t q = 0; q < 9; q++) U[q] = E[q];
-    svd_lane(U, 3, 3, S, V, tmp);
+    double U[9], V[9], Ut[9], Vt[9], Wt[9], T[9];
+    {
+      double Ur[3][3], Sr[3], Vr[3][3];
+#pragma unroll
+      for (int32_t i = 0; i < 3; i++)
+#pragma unroll
+        for (int32_t q = 0; q < 3; q++) Ur[i][q] = E[i * 3 + q];
+      svd_static<3, 3>(Ur, Sr, Vr);
+#pragma unroll
+      for (int32_t i = 0; i < 3; i++)
+#pragma unroll
+        for (int32_t q = 0; q < 3; q++) { U[i * 3 + q] = Ur[i][q]; V[i * 3 + q] = Vr[i][q]; }
+    }
     transpose3(U, Ut); transpose3(V, Vt); transpose3(Wm, Wt);
     matmul(U, 3, 3, Zm, 3, T1); matmul(T1, 3, 3, Ut, 3, T);
     double *Ra = sM, *Rb = sM + 9, *t0 = sM + 18;
@@ -730,16 +765,18 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
     int32_t good = 0;
     for (int32_t i = tid; i < N; i += MONO_T) {
       const vh_p_match &m = L.pm[i];
-      double J[16], w4[4], V4[16], tmp[12];
+      double J[4][4], w4[4], V4[4][4], x[4];
+#pragma unroll
       for (int32_t j = 0; j < 4; j++) {
-        J[0 * 4 + j] = sK[2 * 4 + j] * m.u1p - sK[0 * 4 + j];
-        J[1 * 4 + j] = sK[2 * 4 + j] * m.v1p - sK[1 * 4 + j];
-        J[2 * 4 + j] = sP[c][2 * 4 + j] * m.u1c - sP[c][0 * 4 + j];
-        J[3 * 4 + j] = sP[c][2 * 4 + j] * m.v1c - sP[c][1 * 4 + j];
+        J[0][j] = sK[2 * 4 + j] * m.u1p - sK[0 * 4 + j];
+        J[1][j] = sK[2 * 4 + j] * m.v1p - sK[1 * 4 + j];
+        J[2][j] = sP[c][2 * 4 + j] * m.u1c - sP[c][0 * 4 + j];
+        J[3][j] = sP[c][2 * 4 + j] * m.v1c - sP[c][1 * 4 + j];
       }
-      svd_lane(J, 4, 4, w4, V4, tmp);
-      double x[4], a = 0.0, b = 0.0;
-      for (int32_t j = 0; j < 4; j++) { x[j] = V4[j * 4 + 3]; Xc[(int64_t)j * cap + i] = x[j]; }
+      svd_static_last_v<4, 4>(J, w4, V4, x);  // in registers: the direction of the smallest singular value
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int32_t j = 0; j < 4; j++) Xc[(int64_t)j * cap + i] = x[j];
       for (int32_t j = 0; j < 4; j++) a += sK[2 * 4 + j] * x[j];
       for (int32_t j = 0; j < 4; j++) b += sP[c][2 * 4 + j] * x[j];
       good += (a * x[3] > 0 && b * x[3] > 0) ? 1 : 0;

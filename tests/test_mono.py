@@ -86,6 +86,18 @@ def test_oracle_svd_golden(ob, oracle):
     assert k >= 7
 
 
+def test_static_svd_header_equals_the_oracle(ob, oracle, tmp_path):
+    """csrc/svd_static.h (what the mono kernels factorize 3x3 / 4x4 systems with, in registers) compiled for the
+    host: bit-identical to the oracle's Matrix::svd restatement on 7 500 matrices (tests/cpp/svd_static_check.cpp)."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "svd_static_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "svd_static_check.cpp"),
+                           ob.ORACLE_SO, "-lm", "-Wl,-rpath," + os.path.dirname(ob.ORACLE_SO), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("0 mismatching") == 3, r.stdout + r.stderr
+
+
 def _rand8(ob, iters, n_sets):
     r = ob.glibc_rand_after_srand0(8 * iters).reshape(iters, 8)
     return np.stack([r] * n_sets)
