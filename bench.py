@@ -248,7 +248,11 @@ def main():
     if use_dist:
         # RCCL only carries the barrier and the MAX-reduced timing: streams never exchange data
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")  # (only the single-process rehearsal lacks it; torch.distributed.run sets it)
+        if "MASTER_PORT" not in os.environ:  # (only the single-process rehearsal lacks it; torch.distributed.run sets it)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # which device every rank really sits on: (rank, local rank, device index, PCI bus id), gathered to rank 0
     props = torch.cuda.get_device_properties(local_rank)
