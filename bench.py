@@ -360,7 +360,7 @@ def main():
     # estimateMotion (src/viso_stereo.cpp:40-51).  The Delaunay vote is host work: step t's
     # vote + bucketing run on the host threads while the GPU computes step t+1, then the batched egomotion kernel.
     e2e = None
-    if not args.no_e2e and args.workload == "kitti":
+    if not args.no_e2e and args.workload == "kitti" and world == 1:  # (like cpu_baseline: a context measurement of the N = 1 run)
         nthr = max(1, min(len(os.sched_getaffinity(0)), 16))
         ego = pkg.EgoParams.default(f=645.24, cu=635.96, cv=194.13, base=0.5707)
         r3 = np.random.default_rng(7).integers(0, 2 ** 31 - 1, (S, ego.ransac_iters, 3)).astype(np.int32)
