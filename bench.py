@@ -47,6 +47,7 @@ KERNELS = ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill", "b
 
 
 NOISE = 0  # --noise: grey levels of uniform sensor noise added to every frame (context runs only)
+NOISE_FRAC = 1.0  # --noise-frac: share of the pixels that receive it
 
 
 def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
@@ -63,7 +64,10 @@ def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
             if NOISE:
                 rng = np.random.default_rng(seed * 1000 + k)
                 for i_ in range(2):
-                    im = np.clip(pr[i_].astype(np.int32) + rng.integers(-NOISE, NOISE + 1, pr[i_].shape), 0, 255).astype(np.uint8)
+                    nz = rng.integers(-NOISE, NOISE + 1, pr[i_].shape)
+                    if NOISE_FRAC < 1.0:
+                        nz = nz * (rng.random(pr[i_].shape) < NOISE_FRAC)
+                    im = np.clip(pr[i_].astype(np.int32) + nz, 0, 255).astype(np.uint8)
                     im[:, W:] = 0
                     pr[i_] = im
             cache[(seed, k)] = tuple(pr)
@@ -218,14 +222,16 @@ def main():
                     "(many more, mostly unmatched features; the driver's line is noise 0, the BASELINE workload)")
     ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps steps each (0: as many as make the timed region >= 0.5 s, "
                     "at least 3); every block is bracketed by the barrier + synchronize fence, the median block is reported")
+    ap.add_argument("--noise-frac", type=float, default=1.0, help="context runs: share of the pixels that receive --noise")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the as-shipped-loop measurement (e2e_matchfeatures)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
     args = ap.parse_args()
-    global W, H, NOISE
+    global W, H, NOISE, NOISE_FRAC
     NOISE = args.noise
+    NOISE_FRAC = args.noise_frac
     wl = WORKLOADS[args.workload]
     W, H = wl["W"], wl["H"]
     if args.streams <= 0:

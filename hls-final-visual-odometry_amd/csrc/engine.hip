@@ -85,10 +85,11 @@ struct Group {
   // Loop policy of the searches (match()): speculative (no accept test in the loop, the winner
   // verified, failures searched again) or tested.  The speculative loop is ~12 % faster when
   // almost every query's best candidate lies inside its window (0.5 % re-searched on the
-  // benchmark frames) and slower once more than ~4 % fail (noisy images full of features
-  // without a partner).  Every launch reports (re-searched, searched) with a lag of one or two
-  // steps; above 3 % the tested loop takes over and the speculative one is probed every 16th
-  // launch, below 2 % it comes back.  Results never depend on the choice.
+  // benchmark frames) and slower once more than ~6 % fail (noisy images full of features
+  // without a partner; measured round 3 with grouped second searches: +10 % at 3.3 % re-searched,
+  // +3 % at 4.8 %, -1 % at 6.6 %, -6 % at 8.9 %).  Every launch reports (re-searched, searched)
+  // with a lag of one or two steps; above 6.5 % the tested loop takes over and the speculative
+  // one is probed every 16th launch, below 5.5 % it comes back.  Results never depend on the choice.
   bool stats_pending[2] = {false, false}, stats_was_spec[2] = {false, false};
   int32_t probe_countdown = 0, force_mode = -1;
   bool spec_mode = true;
@@ -536,8 +537,8 @@ struct Group {
       for (int32_t s = 0; s < S; s++) { again += h_out[sl][s].z; searched += h_out[sl][s].w; }
       if (!stats_was_spec[sl] || searched <= 0) continue;  // the tested loop reports nothing
       last_redo_rate = (double)again / (double)searched;
-      if (spec_mode && last_redo_rate > 0.03) { spec_mode = false; probe_countdown = 16; }
-      else if (!spec_mode && last_redo_rate < 0.02) spec_mode = true;
+      if (spec_mode && last_redo_rate > 0.065) { spec_mode = false; probe_countdown = 16; }
+      else if (!spec_mode && last_redo_rate < 0.055) spec_mode = true;
     }
     if (spec_mode) return true;
     if (--probe_countdown <= 0) { probe_countdown = 16; return true; }  // probe

@@ -549,6 +549,47 @@ def test_flow_search_tested_loop_path(gpu):
 
 
 @pytest.mark.gpu
+def test_search_loop_policy_follows_the_data(pkg, ob, oracle, gpu, monkeypatch):
+    """engine.hip: choose_loop.  Frames whose features have partners keep the speculative search loops
+    (few winners fall outside their window); independent noise images -- no feature has a partner -- push
+    the observed share of second searches far over the 6.5 % threshold and the tested loops take over;
+    partnered frames bring the speculative ones back.  The match lists equal the oracle's in every phase."""
+    monkeypatch.delenv("VH_FLOW_TESTED", raising=False)
+    W, H, S = 512, 192, 3
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    p, po = pkg.Params.default(), ob.Params.default()
+    rng = np.random.default_rng(5)
+    clean = [[pkg.synth.frame(W, H, 2 * (t % 8), t % 4, 4, 6, 900 + s) for s in range(S)] for t in range(24)]
+    noisy = [[rng.integers(0, 256, (H, dims[2]), dtype=np.uint8) for s in range(S)] for t in range(8)]
+
+    def run(g, frames, check_every):
+        prev = None
+        for t, fr in enumerate(frames):
+            g.pushBack(np.stack(fr), None, dims, False)
+            if prev is not None or t > 0:
+                g.matchFeatures(pkg.METHOD_FLOW)
+                if t % check_every == 0:
+                    for s in range(S):
+                        fp, fc = feats_for(oracle, po, dims, [prev[s], fr[s]])
+                        assert g.getMatches(s).tobytes() == oracle.matching(po, dims, 0, m1p=fp, m1c=fc).tobytes()
+                else:
+                    g.getMatches(0)  # completes the step, so that its statistics are visible to the next one
+            prev = fr
+
+    g = pkg.StreamGroup(S, p)
+    run(g, clean[:6], 3)
+    spec, rate = g.searchStats()
+    assert spec and 0 <= rate < 0.055, (spec, rate)
+    run(g, noisy, 4)
+    spec, rate = g.searchStats()
+    assert not spec and rate > 0.065, (spec, rate)
+    run(g, clean[6:], 6)  # the 16th launch probes the speculative form and finds it cheap again
+    spec, rate = g.searchStats()
+    assert spec and rate < 0.055, (spec, rate)
+    g.close()
+
+
+@pytest.mark.gpu
 def test_index_invariants_on_the_checking_build(pkg, gpu):
     """libviso_hip_check.so (-DVH_CHECK) verifies on the device every index the shipped kernels
     use unclamped -- row index -> bin position -> record, stage slots, winner positions
