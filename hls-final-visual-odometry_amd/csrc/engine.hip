@@ -205,7 +205,7 @@ struct Group {
     stats_pending[0] = stats_pending[1] = false;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
     d_ego_rand = nullptr; d_ego_ok = nullptr; d_ego_xyz = nullptr; d_ego_tr = nullptr; ego_rand_n = 0;
-    d_mono_scratch = nullptr; d_mono_rand = nullptr; mono_rand_n = 0;
+    d_mono_scratch = nullptr; d_mono_rand = nullptr; mono_rand_n = 0; mono_scratch_iters = 0;
     d_bucket = nullptr; d_bcnt = nullptr; bcap = 0; d_post_rand = nullptr; post_rand_n = 0; d_post_xyz = nullptr; d_post_tr = nullptr; d_post_ok = nullptr;
     if (h_bucket) { (void)hipHostFree(h_bucket); h_bucket = nullptr; }
     if (h_bcnt) { (void)hipHostFree(h_bcnt); h_bcnt = nullptr; }
@@ -793,13 +793,16 @@ struct Group {
   uint8_t *d_mono_scratch = nullptr;
   int32_t *d_mono_rand = nullptr;
   size_t mono_rand_n = 0;
+  int32_t mono_scratch_iters = 0;
   int32_t estimate_motion_mono(const vh_mono_params *e, const int32_t *rand8, double *tr, int32_t *ok, int32_t *ninl) {
     if (!e || !rand8 || !tr || !ok || !ninl || e->ransac_iters < 1) return VH_ERR_INVALID_ARG;
     if (!allocated || (last_method != VH_METHOD_FLOW && last_method != VH_METHOD_QUAD)) return VH_ERR_STATE;
     const size_t nr = (size_t)S * e->ransac_iters * 8;
     int32_t rc;
-    if (!d_mono_scratch) {
-      if ((rc = dmalloc(&d_mono_scratch, (size_t)vh_mono_scratch_bytes(S, mcap), false))) return rc;
+    if ((int64_t)S * e->ransac_iters > (int64_t)1 << 31) return VH_ERR_UNSUPPORTED;
+    if (!d_mono_scratch || mono_scratch_iters < e->ransac_iters) {
+      if ((rc = dmalloc(&d_mono_scratch, (size_t)vh_mono_scratch_bytes(S, mcap, e->ransac_iters), false))) return rc;
+      mono_scratch_iters = e->ransac_iters;
       if (!d_ego_tr) {
         if ((rc = dmalloc(&d_ego_tr, 6 * (size_t)S, false))) return rc;
         if ((rc = dmalloc(&d_ego_ok, 2 * (size_t)S, false))) return rc;
@@ -1432,6 +1435,7 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
   }
   const int64_t total = offsets[n_sets], cap = std::max<int64_t>(nmax, 1);
   if (total > 0 && !pm) return VH_ERR_INVALID_ARG;
+  if ((int64_t)n_sets * e->ransac_iters > (int64_t)1 << 31) return VH_ERR_UNSUPPORTED;
   const int32_t rc = select_device(device);
   if (rc) return rc;
   const size_t nr = (size_t)n_sets * e->ransac_iters * 8;
@@ -1439,7 +1443,7 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
   // one allocation: matches | offsets | rand8 | ok,ninl | inliers | tr | per-list scratch
   const size_t b_pm = sizeof(vh_p_match) * (size_t)std::max<int64_t>(total, 1), b_off = sizeof(int32_t) * ((size_t)n_sets + 1);
   const size_t b_r = sizeof(int32_t) * nr, b_ok = sizeof(int32_t) * 2 * (size_t)n_sets, b_inl = sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1);
-  const size_t b_tr = sizeof(double) * 6 * (size_t)n_sets, b_scr = (size_t)vh_mono_scratch_bytes(n_sets, cap);
+  const size_t b_tr = sizeof(double) * 6 * (size_t)n_sets, b_scr = (size_t)vh_mono_scratch_bytes(n_sets, cap, e->ransac_iters);
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t o_off = up(b_pm), o_r = o_off + up(b_off), o_ok = o_r + up(b_r), o_inl = o_ok + up(b_ok), o_tr = o_inl + up(b_inl), o_scr = o_tr + up(b_tr);
   VH_HIP(hipMalloc((void **)&d, o_scr + b_scr));

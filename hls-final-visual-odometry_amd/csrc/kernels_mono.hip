@@ -265,13 +265,14 @@ __device__ void transpose3(const double *A, double *T) {
 }
 // Matrix::svd of a 3x3 followed by U * diag(W with W[2] = 0) * ~V (src/viso_mono.cpp:262-265, :91-94).
 // The factors live in registers (svd_static.h: every index static after unrolling).
-__device__ void rank2_3x3(const double *M, double *out) {
+// (returns svd_static's zero-pivot flag, see fundamental8)
+__device__ bool rank2_3x3(const double *M, double *out) {
   double U[3][3], w[3], V[3][3], a[9], D[9], UD[9], Vt[9];
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) U[i][j] = M[i * 3 + j];
-  svd_static<3, 3>(U, w, V);
+  const bool zero_pivot = svd_static<3, 3>(U, w, V);
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -279,6 +280,7 @@ __device__ void rank2_3x3(const double *M, double *out) {
   D[0] = w[0]; D[4] = w[1]; D[8] = 0.0;
   matmul(a, 3, 3, D, 3, UD);
   matmul(UD, 3, 3, Vt, 3, out);
+  return zero_pivot;
 }
 
 // Matrix::det of a 3x3 (src/matrix.cpp:400-415) over Matrix::lu (:514-572)
@@ -321,6 +323,26 @@ __device__ double det3(const double *M) {
   return d;
 }
 
+// -DVH_MONO_TIMING: workgroup 0 of mono_final adds the 100 MHz clock ticks of its phases to g_mono_t (tools/mono_phases.py)
+__device__ unsigned long long g_mono_t[16];
+#ifdef VH_MONO_TIMING
+#define VH_MTICK_INIT unsigned long long mt_prev_ = wall_clock64()
+#define VH_MTICK(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_mono_t[k], now_ - mt_prev_); mt_prev_ = now_; } } while (0)
+#else
+#define VH_MTICK_INIT do { } while (0)
+#define VH_MTICK(k) do { } while (0)
+#endif
+
+struct __attribute__((aligned(16))) MonoPoint { double u1, v1, u2, v2; };  // normalised (u1p, v1p, u1c, v1c) as doubles
+
+// hdr slots written by mono_final_a for mono_tri / mono_final_c
+#define MONO_H_GO 32      /* 1: the later kernels have work (0: mono_final_a already reported the failure) */
+#define MONO_H_NBEST 33
+#define MONO_H_RT 34      /* Ra[9], Rb[9], t0[3] */
+#define MONO_H_P2 56      /* P2 of the four (R, t) candidates, [4][12] */
+#define MONO_H_P1 104     /* [K | 0], [12] */
+#define MONO_H_CNT 116    /* int32[4]: points in front of both cameras per candidate */
+
 struct MonoList {
   const vh_p_match *pm;  // the list's matches
   int32_t n;
@@ -329,12 +351,12 @@ struct MonoList {
   double *X;             // [4 solutions][4][cap] triangulated points
   double *d, *dist;      // [cap] ground-plane coordinate / L1 distance of the points in front
   int32_t *idx;          // [cap] inlier indices of the winner
-  double *hdr;           // [32] per list: Tp[9], Tc[9], status
+  double *hdr;           // [128] per list: Tp[9], Tc[9], [18] status; from [32] what mono_final's three kernels hand on (MONO_H_*)
   unsigned long long *key;
 };
 
-// bytes of scratch per list: pn 16*cap | A 72*cap | X 128*cap | d 8*cap | dist 8*cap | idx 4*cap | hdr 256 | key 8, rounded to 16
-__host__ __device__ inline int64_t mono_per_list(int64_t cap) { return (236 * cap + 256 + 8 + 15) / 16 * 16; }
+// bytes of scratch per list: pn 16*cap | A 72*cap | X 128*cap | d 8*cap | dist 8*cap | idx 4*cap | hdr 1024 | key 8, rounded to 16
+__host__ __device__ inline int64_t mono_per_list(int64_t cap) { return (236 * cap + 1024 + 8 + 15) / 16 * 16; }
 
 __device__ __forceinline__ MonoList mono_list(int32_t s, const vh_p_match *pm_base, int64_t pm_stride, const int32_t *offsets,
                                               const int32_t *counts, int32_t count_cap, uint8_t *scratch, int64_t cap) {
@@ -347,10 +369,35 @@ __device__ __forceinline__ MonoList mono_list(int32_t s, const vh_p_match *pm_ba
   L.X = (double *)b; b += 128 * cap;
   L.d = (double *)b; b += 8 * cap;
   L.dist = (double *)b; b += 8 * cap;
-  L.hdr = (double *)b; b += 256;
+  L.hdr = (double *)b; b += 1024;
   L.key = (unsigned long long *)b; b += 8;
   L.idx = (int32_t *)b;
   return L;
+}
+
+// Behind the lists: the queue of hypotheses whose inliers the signed kernel has to count (mono_hyp): count, then entries s * iters + k.
+__device__ __forceinline__ uint32_t *mono_queue(uint8_t *scratch, int32_t n_sets, int64_t cap) {
+  return (uint32_t *)(scratch + (int64_t)n_sets * mono_per_list(cap));
+}
+__host__ __device__ inline int64_t mono_queue_bytes(int32_t n_sets, int32_t iters) { return 16 + ((int64_t)n_sets * iters * 4 + 15) / 16 * 16; }
+// ... and behind the queue every hypothesis' F (+-F from the fast kernel), [n_sets * iters][9]: mono_final lists the
+// winner's inliers with it instead of factorizing the winner's 8-point system again on one lane (125 us of latency).
+__device__ __forceinline__ double *mono_hyp_F(uint8_t *scratch, int32_t n_sets, int64_t cap, int32_t iters) {
+  return (double *)(scratch + (int64_t)n_sets * mono_per_list(cap) + mono_queue_bytes(n_sets, iters));
+}
+
+// s + term(0) + term(1) + .. in this order, terms at T[k * 4 + c] (the loads of a trip are independent of the chain: chain_sum)
+__device__ __forceinline__ double chain_sum4(const double *T, int c, int m, double s) {
+  int k = 0;
+  for (; k + 8 <= m; k += 8) {
+    double t[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) t[q] = T[(k + q) * 4 + c];
+#pragma unroll
+    for (int q = 0; q < 8; q++) s += t[q];
+  }
+  for (; k < m; k++) s += T[k * 4 + c];
+  return s;
 }
 
 // ------------------------------------------------------------------ mono_norm
@@ -359,19 +406,30 @@ __device__ __forceinline__ MonoList mono_list(int32_t s, const vh_p_match *pm_ba
 __global__ void __launch_bounds__(MONO_T)
 mono_norm_kernel(const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
                  const int32_t *__restrict__ counts, int32_t count_cap, uint8_t *__restrict__ scratch, int64_t cap) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *mono_queue(scratch, gridDim.x, cap) = 0u;  // (hypotheses for the signed recount, mono_hyp)
   __shared__ double sC[4], sS[2];
+  // The sums of normalizeFeaturePoints are sequential chains over the matches (their order is part of the result):
+  // the terms of a block of matches are fetched by all lanes into LDS, then one lane per sum walks them (chain_sum4).
+  constexpr int32_t NB = 1024;
+  __shared__ double sTerm[NB * 4];
   const int32_t s = blockIdx.x, tid = threadIdx.x;
   const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
   const int32_t N = L.n;
   if (tid == 0) { *L.key = 0ull; L.hdr[18] = 0.0; }
   if (N < 10) return;  // src/viso_mono.cpp:45-46
-  if (tid < 4) {       // centroids: one sequential sum per lane
+  {                    // centroids: one sequential sum per lane
     double c = 0;
-    for (int32_t i = 0; i < N; i++) {
-      const vh_p_match &m = L.pm[i];
-      c += (double)(tid == 0 ? m.u1p : tid == 1 ? m.v1p : tid == 2 ? m.u1c : m.v1c);
+    for (int32_t b0 = 0; b0 < N; b0 += NB) {
+      const int32_t nb = min(NB, N - b0);
+      for (int32_t i = tid; i < nb; i += MONO_T) {
+        const vh_p_match &m = L.pm[b0 + i];
+        sTerm[i * 4 + 0] = (double)m.u1p; sTerm[i * 4 + 1] = (double)m.v1p; sTerm[i * 4 + 2] = (double)m.u1c; sTerm[i * 4 + 3] = (double)m.v1c;
+      }
+      __syncthreads();
+      if (tid < 4) c = chain_sum4(sTerm, tid, nb, c);
+      __syncthreads();
     }
-    sC[tid] = c / (double)N;
+    if (tid < 4) sC[tid] = c / (double)N;
   }
   __syncthreads();
   const double cpu = sC[0], cpv = sC[1], ccu = sC[2], ccv = sC[3];
@@ -385,10 +443,16 @@ mono_norm_kernel(const vh_p_match *__restrict__ pm_base, int64_t pm_stride, cons
     fl[i] = make_float2(sqrtf(q.x * q.x + q.y * q.y), sqrtf(q.z * q.z + q.w * q.w));  // float expressions in the reference
   }
   __syncthreads();
-  if (tid < 2) {
+  {
     double acc = 0;
-    for (int32_t i = 0; i < N; i++) acc += (double)(tid == 0 ? fl[i].x : fl[i].y);
-    sS[tid] = acc;
+    for (int32_t b0 = 0; b0 < N; b0 += NB) {
+      const int32_t nb = min(NB, N - b0);
+      for (int32_t i = tid; i < nb; i += MONO_T) { const float2 v = fl[b0 + i]; sTerm[i * 4 + 0] = (double)v.x; sTerm[i * 4 + 1] = (double)v.y; }
+      __syncthreads();
+      if (tid < 2) acc = chain_sum4(sTerm, tid, nb, acc);
+      __syncthreads();
+    }
+    if (tid < 2) sS[tid] = acc;
   }
   __syncthreads();
   double sp = sS[0], sc = sS[1];
@@ -400,6 +464,9 @@ mono_norm_kernel(const vh_p_match *__restrict__ pm_base, int64_t pm_stride, cons
     q.x = (float)((double)q.x * sp); q.y = (float)((double)q.y * sp);
     q.z = (float)((double)q.z * sc); q.w = (float)((double)q.w * sc);
     L.pn[i] = q;
+    // the same four floats widened once (exact), for mono_hyp's loop over the matches; the refit system's place is free until mono_final
+    MonoPoint d4; d4.u1 = q.x; d4.v1 = q.y; d4.u2 = q.z; d4.v2 = q.w;
+    ((MonoPoint *)L.A)[i] = d4;
   }
   if (tid == 0) {
     double *Tp = L.hdr, *Tc = L.hdr + 9;
@@ -409,35 +476,28 @@ mono_norm_kernel(const vh_p_match *__restrict__ pm_base, int64_t pm_stride, cons
   }
 }
 
-// fundamentalMatrix on the 8 sampled matches (src/viso_mono.cpp:235-266), one lane
-__device__ void fundamental8(const float4 *pn, const int32_t *act, double *F) {
-  double a[72], w[9], v[81], tmp[27], F0[9];
+// fundamentalMatrix on the 8 sampled matches (src/viso_mono.cpp:235-266), one lane.
+// SIGNED = true: F as the reference computes it, bit for bit.
+// SIGNED = false: +F or -F -- the null vector of the 8x9 system is taken without Matrix::svd's sign normalisation,
+//   which is the only consumer of that decomposition's U (72 doubles, its accumulation and half of the plane
+//   rotations: svd_static.h).  Both callers only COUNT / LIST inliers, and the Sampson test is the same for F and
+//   -F as long as the rank-2 projection of -F0 is the exact mirror image of that of F0; the one place where it need
+//   not be (a Householder pivot that is exactly zero) is reported through the return value, and the caller then
+//   takes the signed form.
+template <bool SIGNED>
+__device__ bool fundamental8(const float4 *pn, const int32_t *act, double *F) {
+  double Ur[8][9], wr[9], Vr[9][9], F0[9];
+#pragma unroll
   for (int32_t i = 0; i < 8; i++) {
     const float4 q = pn[act[i]];  // (u1p, v1p, u1c, v1c)
-    double *r = a + 9 * i;
-    r[0] = (double)(q.z * q.x); r[1] = (double)(q.z * q.y); r[2] = (double)q.z;  // float products
-    r[3] = (double)(q.w * q.x); r[4] = (double)(q.w * q.y); r[5] = (double)q.w;
-    r[6] = (double)q.x; r[7] = (double)q.y; r[8] = 1.0;
+    Ur[i][0] = (double)(q.z * q.x); Ur[i][1] = (double)(q.z * q.y); Ur[i][2] = (double)q.z;  // float products
+    Ur[i][3] = (double)(q.w * q.x); Ur[i][4] = (double)(q.w * q.y); Ur[i][5] = (double)q.w;
+    Ur[i][6] = (double)q.x; Ur[i][7] = (double)q.y; Ur[i][8] = 1.0;
   }
-#ifndef VH_MONO_SCRATCH89
-  // In registers (svd_static.h; U entirely, V partly -- the compiler keeps 92 of V's doubles in private memory at
-  // 366 registers): 256 x 400 x 2000 batches 12.6 -> 8.9 ms against the private-memory form below (-DVH_MONO_SCRATCH89).
-  {
-    double Ur[8][9], wr[9], Vr[9][9], lv[9];
-#pragma unroll
-    for (int32_t i = 0; i < 8; i++)
-#pragma unroll
-      for (int32_t q = 0; q < 9; q++) Ur[i][q] = a[i * 9 + q];
-    svd_static_last_v<8, 9>(Ur, wr, Vr, lv);
-#pragma unroll
-    for (int32_t i = 0; i < 9; i++) F0[i] = lv[i];
-    (void)w; (void)v; (void)tmp;
-  }
-#else
-  svd_lane(a, 8, 9, w, v, tmp);
-  for (int32_t i = 0; i < 9; i++) F0[i] = v[i * 9 + 8];
-#endif
-  rank2_3x3(F0, F);
+  if (SIGNED) svd_static_last_v<8, 9>(Ur, wr, Vr, F0);
+  else svd_static_last_v_unsigned<8, 9>(Ur, wr, Vr, F0);
+  const bool zero_pivot = rank2_3x3(F0, F);
+  return !SIGNED && zero_pivot;
 }
 
 // getRandomSample(N, 8) from eight rand() values (src/viso.cpp:96-102)
@@ -463,20 +523,83 @@ __device__ __forceinline__ bool sampson_inlier(const double *F, const float4 q, 
   return fabs(d) < thr;
 }
 
+// The same test for mono_hyp's loop (one lane = one hypothesis, every lane the same match): numerator and denominator
+// as above, operation for operation, but the quotient is formed only when the answer is not already certain.
+// With p = fl(thr * den): n < fl(p * (1 - 2^-50)) implies n / den < thr * (1 - 2^-51), whose rounding is still below
+// thr; n > fl(p * (1 + 2^-50)) implies the rounded quotient is above thr; in between (a band of 2^-49 relative
+// width), for a den outside the range where these error bounds hold, and for NaNs the division decides.
+// Returns 1 / 0, or the answer + 2 when the division has to decide (sampson_settle).
+__device__ __forceinline__ int32_t sampson_inlier_nodiv(const double *F, const MonoPoint q, double thr, double &n, double &den) {
+  const double u1 = q.u1, v1 = q.v1, u2 = q.u2, v2 = q.v2;
+  const double Fx1u = F[0] * u1 + F[1] * v1 + F[2], Fx1v = F[3] * u1 + F[4] * v1 + F[5], Fx1w = F[6] * u1 + F[7] * v1 + F[8];
+  const double Ftx2u = F[0] * u2 + F[3] * v2 + F[6], Ftx2v = F[1] * u2 + F[4] * v2 + F[7];
+  const double x2tFx1 = u2 * Fx1u + v2 * Fx1v + Fx1w;
+  n = x2tFx1 * x2tFx1;
+  den = Fx1u * Fx1u + Fx1v * Fx1v + Ftx2u * Ftx2u + Ftx2v * Ftx2v;
+  const double p = thr * den;
+  // (bitwise, not short-circuit: no control flow in the common case)
+  const int32_t lo = n < p * (1.0 - 0x1p-50) ? 1 : 0, hi = n > p * (1.0 + 0x1p-50) ? 1 : 0;
+  const int32_t certain = (lo | hi) & (den > 1e-200 ? 1 : 0) & (den < 1e200 ? 1 : 0);
+  return lo | ((certain ^ 1) << 1);
+}
+__device__ __forceinline__ int32_t sampson_settle(int32_t r, double n, double den, double thr) {
+  return (r & 2) ? (fabs(n / den) < thr ? 1 : 0) : r;
+}
+
 // ------------------------------------------------------------------- mono_hyp
-__global__ void __launch_bounds__(128)
+// One lane per hypothesis.  The SIGNED = false launch does the work; a hypothesis that meets the mirror-image hazard
+// of fundamental8 (a numerically singular 3x3: noise-free scenes have them, image data hardly ever) does not vote there
+// but is queued, and the SIGNED = true launch behind it counts the queued ones the reference's way into the same key.
+// force_signed (VH_MONO_SIGNED=1, the tests): every hypothesis takes the second launch.
+template <bool SIGNED>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SIGNED ? 1 : 2, SIGNED ? 1 : 2)))  // (the fast form fits 256 registers: two waves per SIMD)
 mono_hyp_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
                 const int32_t *__restrict__ counts, int32_t count_cap, const int32_t *__restrict__ rand8,
-                uint8_t *__restrict__ scratch, int64_t cap) {
-  const int32_t s = blockIdx.y, k = blockIdx.x * 128 + threadIdx.x;
+                uint8_t *__restrict__ scratch, int64_t cap, int32_t n_sets, int32_t force_signed) {
+  uint32_t *queue = mono_queue(scratch, n_sets, cap);
+  int32_t s, k;
+  if (SIGNED) {
+    const uint32_t q = blockIdx.x * 128u + threadIdx.x;
+    if (q >= queue[0]) return;
+    const uint32_t ent = queue[4 + q];
+    s = (int32_t)(ent / (uint32_t)e.ransac_iters); k = (int32_t)(ent % (uint32_t)e.ransac_iters);
+  } else {
+    s = blockIdx.y; k = blockIdx.x * 128 + threadIdx.x;
+  }
   const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
   if (L.hdr[18] == 0.0 || k >= e.ransac_iters) return;
   int32_t act[8];
-  sample8(rand8 + ((int64_t)s * e.ransac_iters + k) * 8, L.n, act);
   double F[9];
-  fundamental8(L.pn, act, F);
+  bool hazard = !SIGNED && force_signed != 0;
+  if (!hazard) {
+    sample8(rand8 + ((int64_t)s * e.ransac_iters + k) * 8, L.n, act);
+    hazard = fundamental8<SIGNED>(L.pn, act, F);
+  }
+  if (hazard) { queue[4 + atomicAdd(queue, 1u)] = (uint32_t)s * (uint32_t)e.ransac_iters + (uint32_t)k; return; }
+  {
+    double *Fk = mono_hyp_F(scratch, n_sets, cap, e.ransac_iters) + ((int64_t)s * e.ransac_iters + k) * 9;
+#pragma unroll
+    for (int32_t q = 0; q < 9; q++) Fk[q] = F[q];
+  }
   int32_t cnt = 0;
-  for (int32_t i = 0; i < L.n; i++) cnt += sampson_inlier(F, L.pn[i], e.inlier_threshold) ? 1 : 0;
+  const MonoPoint *__restrict__ pd = (const MonoPoint *)L.A;
+  const double thr = e.inlier_threshold;
+  int32_t i = 0;
+  for (; i + 4 <= L.n; i += 4) {  // four independent chains per trip
+    double n4[4], d4[4];
+    int32_t r4[4];
+#pragma unroll
+    for (int32_t q = 0; q < 4; q++) r4[q] = sampson_inlier_nodiv(F, pd[i + q], thr, n4[q], d4[q]);
+    if (__builtin_expect(((r4[0] | r4[1] | r4[2] | r4[3]) & 2) != 0, 0)) {
+#pragma unroll
+      for (int32_t q = 0; q < 4; q++) r4[q] = sampson_settle(r4[q], n4[q], d4[q], thr);
+    }
+    cnt += r4[0] + r4[1] + r4[2] + r4[3];
+  }
+  for (; i < L.n; i++) {
+    double n1, d1;
+    cnt += sampson_settle(sampson_inlier_nodiv(F, pd[i], thr, n1, d1), n1, d1, thr);
+  }
   // more inliers win, the earlier hypothesis on ties (strict `>` in iteration order, src/viso_mono.cpp:74);
   // a hypothesis without inliers never replaces the initial empty set
   if (cnt > 0) atomicMax(L.key, ((unsigned long long)cnt << 32) | (unsigned long long)(0x7FFFFFFF - k));
@@ -490,43 +613,69 @@ mono_hyp_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_
 // rotation and column move.  The scalars of the QR phase are advanced redundantly by every lane
 // (same arithmetic, same values), so that phase needs no exchange at all.
 // On return: A = U (sorted, signs flipped), sV[81] = V, and w[9] in every lane.
-__device__ void svd_tall9(double *A, int m, double *sV, double *sX, int *sNeg, double *w, double *col_tmp) {
+// Sequential sum (k ascending, from 0.0) of chain c of the term array T[row][8], rows [k0, m): what a
+// `for (k = k0; k < m; k++) s += term(k)` of the original computes, with the terms formed beforehand by all lanes.
+// One lane per chain; the loads of a trip do not depend on the chain, so they are in flight together and the trip
+// costs eight dependent additions, not eight memory round trips.
+__device__ __forceinline__ double chain_sum(const double *T, int c, int k0, int m) {
+  double s = 0.0;
+  int k = k0;
+  for (; k + 8 <= m; k += 8) {
+    double t[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) t[q] = T[(int64_t)(k + q) * 8 + c];
+#pragma unroll
+    for (int q = 0; q < 8; q++) s += t[q];
+  }
+  for (; k < m; k++) s += T[(int64_t)k * 8 + c];
+  return s;
+}
+
+// T: [m][8] doubles of term scratch (LDS when A is).
+__device__ void svd_tall9(double *A, int m, double *sV, double *sX, int *sNeg, double *w, double *col_tmp, double *T) {
   const int n = 9, tid = threadIdx.x;
   double rv1[9];
   int i, j, k, l = 0;
-  double anorm, f, g, h, s, scale;
+  double anorm, g, h, s, scale;
 #define AA(r, q) A[(int64_t)(r) * 9 + (q)]
 #define VV(r, q) sV[(r) * 9 + (q)]
+#define TT(r, q) T[(int64_t)(r) * 8 + (q)]
   g = scale = anorm = 0.0;
   for (i = 0; i < n; i++) {
     l = i + 1;
     rv1[i] = scale * g;
     g = s = scale = 0.0;
-    // left Householder step on column i (i < m always: m >= 9)
-    if (tid == 0) {
-      double sc = 0.0;
-      for (k = i; k < m; k++) sc += fabs(AA(k, i));
-      sX[0] = sc;
-      if (sc) {
-        double ss = 0.0;
-        for (k = i; k < m; k++) { AA(k, i) /= sc; ss += AA(k, i) * AA(k, i); }
+    // left Householder step on column i (i < m always: m >= 9).  Every sum over the rows is a chain in the original's
+    // order (chain_sum); everything elementwise -- terms, the division by the scale, the update of the columns -- is
+    // spread over the workgroup.
+    for (k = i + tid; k < m; k += MONO_T) TT(k, 0) = fabs(AA(k, i));
+    __syncthreads();
+    if (tid == 0) sX[0] = chain_sum(T, 0, i, m);
+    __syncthreads();
+    scale = sX[0];
+    if (scale) {
+      for (k = i + tid; k < m; k += MONO_T) { const double v = AA(k, i) / scale; AA(k, i) = v; TT(k, 0) = v * v; }
+      __syncthreads();
+      if (tid == 0) {
+        const double ss = chain_sum(T, 0, i, m);
         const double ff = AA(i, i), gg = -sign_of(sqrt(ss), ff);
         sX[1] = gg; sX[2] = ff * gg - ss;
         AA(i, i) = ff - gg;
       }
-    }
-    __syncthreads();
-    scale = sX[0];
-    if (scale) {
+      __syncthreads();
       g = sX[1]; h = sX[2];
-      if (tid >= l && tid < n) {
-        j = tid;
-        for (s = 0.0, k = i; k < m; k++) s += AA(k, i) * AA(k, j);
-        f = s / h;
-        for (k = i; k < m; k++) AA(k, j) += f * AA(k, i);
+      for (k = i + tid; k < m; k += MONO_T) {
+        const double ai = AA(k, i);
+        for (j = l; j < n; j++) TT(k, j - l) = ai * AA(k, j);
       }
       __syncthreads();
-      for (k = i + tid; k < m; k += MONO_T) AA(k, i) *= scale;
+      if (tid < n - l) sX[4 + tid] = chain_sum(T, tid, i, m) / h;
+      __syncthreads();
+      for (k = i + tid; k < m; k += MONO_T) {
+        const double ai = AA(k, i);
+        for (j = l; j < n; j++) AA(k, j) += sX[4 + j - l] * ai;
+        AA(k, i) = ai * scale;
+      }
     }
     __syncthreads();
     w[i] = scale * g;
@@ -562,45 +711,53 @@ __device__ void svd_tall9(double *A, int m, double *sV, double *sX, int *sNeg, d
     const double t = fabs(w[i]) + fabs(rv1[i]);
     anorm = anorm > t ? anorm : t;
   }
-  // accumulation of right-hand transformations: 9 x 9, one lane
-  if (tid == 0) {
+  // accumulation of right-hand transformations: 9 x 9, lane j = column j
+  {
     double gg = g;
     int ll = l;
-    for (i = 0; i < 81; i++) sV[i] = 0.0;
+    for (i = tid; i < 81; i += MONO_T) sV[i] = 0.0;
+    __syncthreads();
     for (i = n - 1; i >= 0; i--) {
       if (i < n - 1) {
         if (gg) {
-          for (j = ll; j < n; j++) VV(j, i) = (AA(i, j) / AA(i, ll)) / gg;
-          for (j = ll; j < n; j++) {
+          if (tid >= ll && tid < n) VV(tid, i) = (AA(i, tid) / AA(i, ll)) / gg;
+          __syncthreads();
+          if (tid >= ll && tid < n) {
+            j = tid;
             double ss = 0.0;
             for (k = ll; k < n; k++) ss += AA(i, k) * VV(k, j);
             for (k = ll; k < n; k++) VV(k, j) += ss * VV(k, i);
           }
+          __syncthreads();
         }
-        for (j = ll; j < n; j++) VV(i, j) = VV(j, i) = 0.0;
+        if (tid >= ll && tid < n) VV(i, tid) = VV(tid, i) = 0.0;
       }
-      VV(i, i) = 1.0;
+      if (tid == 0) VV(i, i) = 1.0;
+      __syncthreads();
       gg = rv1[i];
       ll = i;
     }
   }
-  __syncthreads();
   // accumulation of left-hand transformations
   for (i = n - 1; i >= 0; i--) {
     l = i + 1;
     g = w[i];
-    if (tid == 0) for (j = l; j < n; j++) AA(i, j) = 0.0;
+    if (tid >= l && tid < n) AA(i, tid) = 0.0;
     __syncthreads();
     if (g) {
       g = 1.0 / g;
-      if (tid >= l && tid < n) {
-        j = tid;
-        for (s = 0.0, k = l; k < m; k++) s += AA(k, i) * AA(k, j);
-        f = (s / AA(i, i)) * g;
-        for (k = i; k < m; k++) AA(k, j) += f * AA(k, i);
+      for (k = l + tid; k < m; k += MONO_T) {
+        const double ai = AA(k, i);
+        for (j = l; j < n; j++) TT(k, j - l) = ai * AA(k, j);
       }
       __syncthreads();
-      for (j = i + tid; j < m; j += MONO_T) AA(j, i) *= g;
+      if (tid < n - l) sX[4 + tid] = (chain_sum(T, tid, l, m) / AA(i, i)) * g;
+      __syncthreads();
+      for (k = i + tid; k < m; k += MONO_T) {
+        const double ai = AA(k, i);
+        for (j = l; j < n; j++) AA(k, j) += sX[4 + j - l] * ai;
+        AA(k, i) = ai * g;
+      }
     } else {
       for (j = i + tid; j < m; j += MONO_T) AA(j, i) = 0.0;
     }
@@ -643,21 +800,21 @@ __device__ void svd_tall9(double *A, int m, double *sV, double *sX, int *sNeg, d
   __syncthreads();
 #undef AA
 #undef VV
+#undef TT
 }
 
 __global__ void __launch_bounds__(MONO_T)
-mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
+mono_final_a_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
                   const int32_t *__restrict__ counts, int32_t count_cap, const int32_t *__restrict__ rand8, uint8_t *__restrict__ scratch,
                   int64_t cap, double *__restrict__ tr_out, int32_t *__restrict__ ok_out, int32_t *__restrict__ ninl_out,
                   int32_t *__restrict__ inl_out, int64_t inl_stride) {
-  __shared__ double sF[9], sV[81], sX[16], sM[48];  // sM: R candidates Ra[9], Rb[9], t0[3], P1/P2 rows ...
+  __shared__ double sF[9], sV[81], sX[16];
   // The refit system lives in LDS when it fits (MONO_LDS_ROWS x 9 doubles): the cooperative SVD's sequential sums
   // are chains of dependent accumulations over a column, one load per step -- from global memory each step waited
   // out an L2 round trip (7.8 of the 15 ms a 256 x 400 x 2000 batch took), from LDS a few dozen cycles.
   __shared__ double sA[MONO_LDS_ROWS * 9];
-  __shared__ double sP[4][12];                      // P2 of the four (R, t) candidates
-  __shared__ double sK[12];                         // P1 = [K | 0]
-  __shared__ int32_t sNeg[9], sWave[MONO_T / 64], sBase, sCnt[4], sFlag;
+  __shared__ double sT[MONO_LDS_ROWS * 8];        // the cooperative SVD's term scratch
+  __shared__ int32_t sNeg[9], sWave[MONO_T / 64], sBase;
   const int32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
   const int32_t N = L.n;
@@ -665,21 +822,20 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
   auto fail = [&](int32_t ninl) {
     if (tid == 0) { ok_out[s] = 0; ninl_out[s] = ninl; for (int32_t q = 0; q < 6; q++) tr_out[6 * s + q] = 0.0; }
   };
+  if (tid == 0) L.hdr[MONO_H_GO] = 0.0;
   if (L.hdr[18] == 0.0) { fail(0); return; }
   const unsigned long long key = *L.key;
   const int32_t nbest = (int32_t)(key >> 32);
   if (nbest == 0) { fail(0); return; }
-  // the winner's F again (same code, same bits as in mono_hyp)
-  if (tid == 0) {
-    const int32_t kbest = 0x7FFFFFFF - (int32_t)(uint32_t)key;
-    int32_t act[8];
-    sample8(rand8 + ((int64_t)s * e.ransac_iters + kbest) * 8, N, act);
-    double F[9];
-    fundamental8(L.pn, act, F);
-    for (int32_t q = 0; q < 9; q++) sF[q] = F[q];
-    sBase = 0;
-  }
+  // the winner's F as mono_hyp left it (+-F: the test below is the same for both)
+  VH_MTICK_INIT;
+#ifdef VH_MONO_TIMING
+  if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_mono_t[15], (unsigned long long)*mono_queue(scratch, gridDim.x, cap));  // queued hypotheses of the call
+#endif
+  if (tid < 9) sF[tid] = mono_hyp_F(scratch, gridDim.x, cap, e.ransac_iters)[((int64_t)s * e.ransac_iters + (0x7FFFFFFF - (int32_t)(uint32_t)key)) * 9 + tid];
+  if (tid == 0) sBase = 0;
   __syncthreads();
+  VH_MTICK(0);  // the winner's F
   // its ordered inlier list (VisualOdometry::inliers)
   {
     double F[9];
@@ -703,6 +859,7 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
     }
   }
   if (nbest < 10) { fail(nbest); return; }  // src/viso_mono.cpp:80-81
+  VH_MTICK(1);  // inlier list
   // F from all inliers: the nbest x 9 system (src/viso_mono.cpp:84, :242-256)
   double *Asys = nbest <= MONO_LDS_ROWS ? sA : L.A;
   for (int32_t i = tid; i < nbest; i += MONO_T) {
@@ -714,7 +871,9 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
   }
   __syncthreads();
   double w9[9];
-  svd_tall9(Asys, nbest, sV, sX, sNeg, w9, L.d);
+  VH_MTICK(2);  // refit system
+  svd_tall9(Asys, nbest, sV, sX, sNeg, w9, L.d, nbest <= MONO_LDS_ROWS ? sT : L.X);
+  VH_MTICK(3);  // its SVD
   if (tid == 0) {
     double F0[9], F[9], T1[9], T2[9], E[9], Kt[9];
     const double K[9] = {e.f, 0, e.cu, 0, e.f, e.cv, 0, 0, 1};
@@ -742,7 +901,7 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
     }
     transpose3(U, Ut); transpose3(V, Vt); transpose3(Wm, Wt);
     matmul(U, 3, 3, Zm, 3, T1); matmul(T1, 3, 3, Ut, 3, T);
-    double *Ra = sM, *Rb = sM + 9, *t0 = sM + 18;
+    double *Ra = L.hdr + MONO_H_RT, *Rb = Ra + 9, *t0 = Ra + 18, *sK = L.hdr + MONO_H_P1;
     matmul(U, 3, 3, Wm, 3, T1); matmul(T1, 3, 3, Vt, 3, Ra);
     matmul(U, 3, 3, Wt, 3, T1); matmul(T1, 3, 3, Vt, 3, Rb);
     t0[0] = T[2 * 3 + 1]; t0[1] = T[0 * 3 + 2]; t0[2] = T[1 * 3 + 0];
@@ -754,35 +913,76 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
       const double *R = c < 2 ? Ra : Rb;
       double Rt[12];
       for (int32_t i = 0; i < 3; i++) { for (int32_t j = 0; j < 3; j++) Rt[i * 4 + j] = R[i * 3 + j]; Rt[i * 4 + 3] = (c & 1) ? -t0[i] : t0[i]; }
-      matmul(K, 3, 3, Rt, 4, sP[c]);
+      matmul(K, 3, 3, Rt, 4, L.hdr + MONO_H_P2 + 12 * c);
     }
-    for (int32_t c = 0; c < 4; c++) sCnt[c] = 0;
+    for (int32_t c = 0; c < 4; c++) ((int32_t *)(L.hdr + MONO_H_CNT))[c] = 0;
+    L.hdr[MONO_H_NBEST] = (double)nbest;
+    L.hdr[MONO_H_GO] = 1.0;
   }
-  __syncthreads();
-  // triangulation of every match under each candidate: one 4x4 Matrix::svd per lane (src/viso_mono.cpp:378-387)
-  for (int32_t c = 0; c < 4; c++) {
+  VH_MTICK(4);  // F, E, R|t candidates (one lane)
+}
+
+// ------------------------------------------------------------------- mono_tri
+// triangulateChieral's linear triangulation (src/viso_mono.cpp:378-387): one lane per (match, candidate) -- one 4x4
+// Matrix::svd each, in registers.  A kernel of its own so that the hundreds to thousands of independent
+// factorizations of a list fill the chip instead of queueing on the 256 lanes of the list's mono_final workgroup.
+__global__ void __launch_bounds__(256)
+mono_tri_kernel(const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
+                const int32_t *__restrict__ counts, int32_t count_cap, uint8_t *__restrict__ scratch, int64_t cap) {
+  const int32_t s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, c = tid & 3;
+  const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
+  if (L.hdr[MONO_H_GO] == 0.0 || blockIdx.x * 64 >= L.n) return;
+  const int32_t i = blockIdx.x * 64 + (tid >> 2);
+  const double *sK = L.hdr + MONO_H_P1, *P2 = L.hdr + MONO_H_P2 + 12 * c;
+  bool good = false;
+  if (i < L.n) {
+    const vh_p_match &m = L.pm[i];
+    double J[4][4], w4[4], V4[4][4], x[4];
+#pragma unroll
+    for (int32_t j = 0; j < 4; j++) {
+      J[0][j] = sK[2 * 4 + j] * m.u1p - sK[0 * 4 + j];
+      J[1][j] = sK[2 * 4 + j] * m.v1p - sK[1 * 4 + j];
+      J[2][j] = P2[2 * 4 + j] * m.u1c - P2[0 * 4 + j];
+      J[3][j] = P2[2 * 4 + j] * m.v1c - P2[1 * 4 + j];
+    }
+    // the direction of the smallest singular value, up to sign (no U: svd_static.h) -- every use of it, here and in
+    // mono_final_c, is a quotient or a product of two components, the same for x and -x
+    svd_static_last_v_unsigned<4, 4>(J, w4, V4, x);
     double *Xc = L.X + (int64_t)c * 4 * cap;
-    int32_t good = 0;
-    for (int32_t i = tid; i < N; i += MONO_T) {
-      const vh_p_match &m = L.pm[i];
-      double J[4][4], w4[4], V4[4][4], x[4];
+    double a = 0.0, b = 0.0;
 #pragma unroll
-      for (int32_t j = 0; j < 4; j++) {
-        J[0][j] = sK[2 * 4 + j] * m.u1p - sK[0 * 4 + j];
-        J[1][j] = sK[2 * 4 + j] * m.v1p - sK[1 * 4 + j];
-        J[2][j] = sP[c][2 * 4 + j] * m.u1c - sP[c][0 * 4 + j];
-        J[3][j] = sP[c][2 * 4 + j] * m.v1c - sP[c][1 * 4 + j];
-      }
-      svd_static_last_v<4, 4>(J, w4, V4, x);  // in registers: the direction of the smallest singular value
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int32_t j = 0; j < 4; j++) Xc[(int64_t)j * cap + i] = x[j];
-      for (int32_t j = 0; j < 4; j++) a += sK[2 * 4 + j] * x[j];
-      for (int32_t j = 0; j < 4; j++) b += sP[c][2 * 4 + j] * x[j];
-      good += (a * x[3] > 0 && b * x[3] > 0) ? 1 : 0;
-    }
-    if (good) atomicAdd(&sCnt[c], good);
+    for (int32_t j = 0; j < 4; j++) Xc[(int64_t)j * cap + i] = x[j];
+    for (int32_t j = 0; j < 4; j++) a += sK[2 * 4 + j] * x[j];
+    for (int32_t j = 0; j < 4; j++) b += P2[2 * 4 + j] * x[j];
+    good = a * x[3] > 0 && b * x[3] > 0;
   }
+  const uint64_t bal = __ballot(good);
+  if (lane < 4) {  // lane c of each wave adds up the wave's lanes of candidate c
+    const int32_t n = __popcll(bal & (0x1111111111111111ull << lane));
+    if (n) atomicAdd((int32_t *)(L.hdr + MONO_H_CNT) + lane, n);
+  }
+}
+
+// --------------------------------------------------------------- mono_final_c
+// The rest of estimateMotion (src/viso_mono.cpp:96-160) on the winning (R, t): points in front, median distance,
+// ground-plane vote, scale, the six motion parameters.
+__global__ void __launch_bounds__(MONO_T)
+mono_final_c_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
+                    const int32_t *__restrict__ counts, int32_t count_cap, uint8_t *__restrict__ scratch, int64_t cap,
+                    double *__restrict__ tr_out, int32_t *__restrict__ ok_out, int32_t *__restrict__ ninl_out) {
+  __shared__ double sX[16], sM[21];
+  __shared__ double sT[MONO_LDS_ROWS * 8];
+  __shared__ int32_t sWave[MONO_T / 64], sBase, sFlag;
+  const int32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
+  if (L.hdr[MONO_H_GO] == 0.0) return;  // (mono_final_a reported the failure)
+  const int32_t N = L.n, nbest = (int32_t)L.hdr[MONO_H_NBEST];
+  const int32_t *sCnt = (const int32_t *)(L.hdr + MONO_H_CNT);
+  auto fail = [&](int32_t ninl) {
+    if (tid == 0) { ok_out[s] = 0; ninl_out[s] = ninl; for (int32_t q = 0; q < 6; q++) tr_out[6 * s + q] = 0.0; }
+  };
+  if (tid < 21) sM[tid] = L.hdr[MONO_H_RT + tid];
+  VH_MTICK_INIT;
   __syncthreads();
   int32_t cbest = -1, max_in = 0;
   for (int32_t c = 0; c < 4; c++) if (sCnt[c] > max_in) { max_in = sCnt[c]; cbest = c; }  // strict `>`, src/viso_mono.cpp:353
@@ -818,27 +1018,59 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
   }
   const int32_t np = sBase;
   if (np < 10) { fail(nbest); return; }
-  // median = element number np/2 of the sorted distances (smallerThanMedian): its rank by counting
+  VH_MTICK(6);  // points in front, compaction
+  // median = element number np/2 of the sorted distances (smallerThanMedian): its rank by counting.  Both this and
+  // the vote below read the whole list once per element: from LDS (the SVD's term scratch is free) when it fits.
+  const bool staged = np <= MONO_LDS_ROWS * 8;
+  const double *distv = staged ? sT : L.dist;
+  if (staged) {
+    for (int32_t i = tid; i < np; i += MONO_T) sT[i] = L.dist[i];
+    __syncthreads();
+  }
   const int32_t half = np / 2;
   for (int32_t i = tid; i < np; i += MONO_T) {
-    const double v = L.dist[i];
-    int32_t rank = 0;
-    for (int32_t j = 0; j < np; j++) { const double o = L.dist[j]; rank += (o < v || (o == v && j < i)) ? 1 : 0; }
+    const double v = distv[i];
+    int32_t rank = 0, j = 0;
+    for (; j + 8 <= np; j += 8) {  // (eight loads in flight per trip; the count does not care about the order)
+      double o[8];
+#pragma unroll
+      for (int32_t q = 0; q < 8; q++) o[q] = distv[j + q];
+#pragma unroll
+      for (int32_t q = 0; q < 8; q++) rank += (o[q] < v || (o[q] == v && j + q < i)) ? 1 : 0;
+    }
+    for (; j < np; j++) { const double o = distv[j]; rank += (o < v || (o == v && j < i)) ? 1 : 0; }
     if (rank == half) sX[0] = v;
   }
   __syncthreads();
   const double median = sX[0];
   if (median > e.motion_threshold) { fail(nbest); return; }
+  VH_MTICK(7);  // median
   const double sigma = median / 50.0, weight = 1.0 / (2.0 * sigma * sigma);
   // ground-plane vote (src/viso_mono.cpp:130-148): each lane sums the kernel over all j in order for its
   // candidates i (the sums replace the distances, which are dead); the first i with the largest sum wins
+  const double *dv = staged ? sT : L.d;
+  if (staged) {
+    for (int32_t i = tid; i < np; i += MONO_T) sT[i] = L.d[i];
+    __syncthreads();
+  }
   for (int32_t i = tid; i < np; i += MONO_T) {
     double sum = 0;
-    if (L.d[i] > median / e.motion_threshold)
-      for (int32_t j = 0; j < np; j++) { const double q = L.d[j] - L.d[i]; sum += exp(-q * q * weight); }
+    const double di = dv[i];
+    if (di > median / e.motion_threshold) {
+      int32_t j = 0;
+      for (; j + 4 <= np; j += 4) {  // four independent exponentials per trip, added in the original's order
+        double t[4];
+#pragma unroll
+        for (int32_t q = 0; q < 4; q++) { const double dq = dv[j + q] - di; t[q] = exp(-dq * dq * weight); }
+#pragma unroll
+        for (int32_t q = 0; q < 4; q++) sum += t[q];
+      }
+      for (; j < np; j++) { const double q = dv[j] - di; sum += exp(-q * q * weight); }
+    }
     L.dist[i] = sum;
   }
   __syncthreads();
+  VH_MTICK(8);  // ground-plane vote
   if (tid == 0) {
     double best_sum = 0;
     int32_t best_idx = 0;
@@ -865,16 +1097,29 @@ mono_final_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int6
 
 }  // namespace
 
-int64_t vh_mono_scratch_bytes(int32_t n_sets, int64_t cap) {
-  return (int64_t)n_sets * mono_per_list(cap);
+extern "C" int32_t vh_debug_mono_timing(unsigned long long *out, int32_t reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mono_t), sizeof(g_mono_t)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mono_t), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+
+int64_t vh_mono_scratch_bytes(int32_t n_sets, int64_t cap, int32_t ransac_iters) {
+  return (int64_t)n_sets * mono_per_list(cap) + mono_queue_bytes(n_sets, ransac_iters) + (int64_t)n_sets * ransac_iters * 72;  // lists | queue | F of every hypothesis
 }
 
 void vh_launch_mono(const vh_mono_params &e, int32_t n_sets, const vh_p_match *pm, int64_t pm_stride, const int32_t *offsets,
                     const int32_t *counts, int32_t count_cap, const int32_t *rand8, uint8_t *scratch, int64_t cap, double *tr,
                     int32_t *ok, int32_t *ninl, int32_t *inl, int64_t inl_stride, hipStream_t st) {
   hipLaunchKernelGGL(mono_norm_kernel, dim3(n_sets), dim3(MONO_T), 0, st, pm, pm_stride, offsets, counts, count_cap, scratch, cap);
-  hipLaunchKernelGGL(mono_hyp_kernel, dim3((e.ransac_iters + 127) / 128, n_sets), dim3(128), 0, st, e, pm, pm_stride, offsets, counts,
-                     count_cap, rand8, scratch, cap);
-  hipLaunchKernelGGL(mono_final_kernel, dim3(n_sets), dim3(MONO_T), 0, st, e, pm, pm_stride, offsets, counts, count_cap, rand8, scratch,
+  static const int32_t force_signed = [] { const char *v = getenv("VH_MONO_SIGNED"); return v && atoi(v) ? 1 : 0; }();
+  const dim3 hgrid((e.ransac_iters + 127) / 128, n_sets);
+  hipLaunchKernelGGL(mono_hyp_kernel<false>, hgrid, dim3(128), 0, st, e, pm, pm_stride, offsets, counts, count_cap, rand8, scratch, cap, n_sets, force_signed);
+  // (sized for a full queue; the workgroups beyond its length return at once)
+  hipLaunchKernelGGL(mono_hyp_kernel<true>, dim3((uint32_t)(((int64_t)n_sets * e.ransac_iters + 127) / 128)), dim3(128), 0, st, e, pm, pm_stride, offsets,
+                     counts, count_cap, rand8, scratch, cap, n_sets, force_signed);
+  hipLaunchKernelGGL(mono_final_a_kernel, dim3(n_sets), dim3(MONO_T), 0, st, e, pm, pm_stride, offsets, counts, count_cap, rand8, scratch,
                      cap, tr, ok, ninl, inl, inl_stride);
+  // (sized for lists as long as the capacity; the workgroups beyond a list's length return at once)
+  hipLaunchKernelGGL(mono_tri_kernel, dim3((uint32_t)((cap + 63) / 64), n_sets), dim3(256), 0, st, pm, pm_stride, offsets, counts, count_cap, scratch, cap);
+  hipLaunchKernelGGL(mono_final_c_kernel, dim3(n_sets), dim3(MONO_T), 0, st, e, pm, pm_stride, offsets, counts, count_cap, scratch, cap, tr, ok, ninl);
 }

@@ -9,10 +9,23 @@
 #endif
 
 // Everything up to (not including) the sort: U, w, V as the diagonalisation leaves them.
-template <int M, int N>
-SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]) {
+// WANT_U = false leaves out what only U needs -- the accumulation of the left-hand transformations and the
+// column rotations of U in the diagonalisation; neither feeds back into w, rv1 or V (the rotation angles are
+// functions of w and rv1 alone), so w and V come out bit for bit as with WANT_U = true and U is left as the
+// Householder reduction's scratch.
+// Returns whether the decomposition of -A may fail to be the exact mirror image of that of A (what the callers of
+// svd_static_last_v_unsigned rely on): a Householder pivot f that is exactly zero (sgn(a, f) takes +0 and -0 alike),
+// or an exactly vanishing w[i] / rv1[i] in the accumulation of the transformations, where the column is replaced by a
+// unit vector whose sign is not tied to the sign of A, a cancellation rotation of the diagonalisation (taken when
+// a w[l-1] is negligible: from then on the sign of that column of U is arbitrary and later sweeps mix it back in
+// at the 1e-16 level), or a vanishing z in a sweep.  All of these need a numerically singular A; tests/cpp/
+// svd_static_check.cpp checks that unflagged 3x3 inputs -- random, integer, skew-like, exactly rank-deficient --
+// have exact mirror images.  (With WANT_U = false the w[i] of the left-hand accumulation is not looked at.)
+template <int M, int N, bool WANT_U = true>
+SVD_HD bool svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]) {
   constexpr int MN = M < N ? M : N;
   double rv1[N];
+  bool zero_pivot = false;
   double anorm = 0.0, g = 0.0, scale = 0.0;
   auto sgn = [](double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); };
   auto pyth = [](double a, double b) {
@@ -40,6 +53,7 @@ SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]
 #pragma unroll
         for (int k = i; k < M; k++) { U[k][i] /= scale; s += U[k][i] * U[k][i]; }
         double f = U[i][i];
+        zero_pivot = zero_pivot || f == 0.0;
         g = -sgn(sqrt(s), f);
         const double h = f * g - s;
         U[i][i] = f - g;
@@ -65,6 +79,7 @@ SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]
 #pragma unroll
         for (int k = l; k < N; k++) { U[i][k] /= scale; s += U[i][k] * U[i][k]; }
         const double f = U[i][l < N ? l : 0];
+        zero_pivot = zero_pivot || f == 0.0;
         g = -sgn(sqrt(s), f);
         const double h = f * g - s;
         U[i][l < N ? l : 0] = f - g;
@@ -90,6 +105,7 @@ SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]
   for (int i = N - 1; i >= 0; i--) {
     const int l = i + 1;
     if (i < N - 1) {
+      zero_pivot = zero_pivot || g == 0.0;
       if (g) {
 #pragma unroll
         for (int j = l; j < N; j++) V[j][i] = (U[i < M ? i : 0][j] / U[i < M ? i : 0][l < N ? l : 0]) / g;
@@ -109,10 +125,12 @@ SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]
     g = rv1[i];
   }
   // accumulation of left-hand transformations
+  if (WANT_U)
 #pragma unroll
   for (int i = MN - 1; i >= 0; i--) {
     const int l = i + 1;
     g = w[i];
+    zero_pivot = zero_pivot || g == 0.0;
 #pragma unroll
     for (int j = l; j < N; j++) U[i][j] = 0.0;
     if (g) {
@@ -161,12 +179,14 @@ SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]
             rv1[i] = c * rv1[i];
             if ((double)(fabs(f) + anorm) == anorm) brk = true;
             else {
+              zero_pivot = true;  // w[l-1] was negligible, not zero: the sign of column l-1 is no longer tied to that of A
               g = w[i];
               double h = pyth(f, g);
               w[i] = h;
               h = 1.0 / h;
               c = g * h;
               s = -f * h;
+              if (WANT_U)
 #pragma unroll
               for (int a = 0; a < i; a++)
                 if (a == l - 1) {
@@ -220,9 +240,10 @@ SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]
             for (int r = 0; r < N; r++) { const double xx = V[r][j], zz = V[r][i]; V[r][j] = xx * c + zz * s; V[r][i] = zz * c - xx * s; }
             z = pyth(f, h);
             w[j] = z;
-            if (z) { z = 1.0 / z; c = f * z; s = h * z; }
+            if (z) { z = 1.0 / z; c = f * z; s = h * z; } else zero_pivot = true;  // (the rotation of U keeps V's c, s)
             f = c * g + s * y;
             x = c * y - s * g;
+            if (WANT_U)
 #pragma unroll
             for (int r = 0; r < M; r++) { const double yy = U[r][j], zz = U[r][i]; U[r][j] = yy * c + zz * s; U[r][i] = zz * c - yy * s; }
           }
@@ -235,6 +256,7 @@ SVD_HD void svd_static_core(double (&U)[M][N], double (&w)[N], double (&V)[N][N]
       }
     }
   }
+  return zero_pivot;
 }
 
 // The shell sort of the singular values (src/matrix.cpp:770-790) on w alone: w sorted (decreasing), perm[d] = the
@@ -274,8 +296,8 @@ SVD_HD void svd_static_sort(double (&w)[N], int (&perm)[N]) {
 
 // The whole Matrix::svd: U (M x N factor), w, V sorted and sign-normalised as the reference returns them.
 template <int M, int N>
-SVD_HD void svd_static(double (&U)[M][N], double (&w)[N], double (&V)[N][N]) {
-  svd_static_core<M, N>(U, w, V);
+SVD_HD bool svd_static(double (&U)[M][N], double (&w)[N], double (&V)[N][N]) {
+  const bool zero_pivot = svd_static_core<M, N>(U, w, V);
   int perm[N];
   svd_static_sort<N>(w, perm);
   {
@@ -315,6 +337,7 @@ SVD_HD void svd_static(double (&U)[M][N], double (&w)[N], double (&V)[N][N]) {
       for (int r = 0; r < N; r++) V[r][k] = -V[r][k];
     }
   }
+  return zero_pivot;
 }
 
 // Only the LAST column of the sorted, sign-normalised V (the direction of the smallest singular value): what the
@@ -335,5 +358,22 @@ SVD_HD void svd_static_last_v(double (&U)[M][N], double (&w)[N], double (&V)[N][
       const bool flip = s2 > (M + N) / 2;
 #pragma unroll
       for (int r = 0; r < N; r++) out[r] = flip ? -V[r][sidx] : V[r][sidx];
+    }
+}
+
+// The direction of the smallest singular value up to SIGN: the column of V that svd_static_last_v would return, without
+// the sign normalisation (which needs U) and therefore without U.  For callers whose result does not depend on the sign
+// of the vector -- the inlier count of a fundamental-matrix hypothesis: F -> -F negates every intermediate of the rank-2
+// projection and of the Sampson test exactly (IEEE arithmetic is symmetric under negation) and the test squares it.
+template <int M, int N>
+SVD_HD void svd_static_last_v_unsigned(double (&U)[M][N], double (&w)[N], double (&V)[N][N], double (&out)[N]) {
+  svd_static_core<M, N, false>(U, w, V);
+  int perm[N];
+  svd_static_sort<N>(w, perm);
+#pragma unroll
+  for (int sidx = 0; sidx < N; sidx++)
+    if (perm[N - 1] == sidx) {
+#pragma unroll
+      for (int r = 0; r < N; r++) out[r] = V[r][sidx];
     }
 }

@@ -198,7 +198,7 @@ void vh_launch_ego(const vh_ego_params &e, int32_t n_sets, const vh_p_match *pm,
                    int32_t *ok, int32_t *ninl, int32_t *inl, int64_t inl_stride, hipStream_t st);
 
 struct vh_mono_params;
-int64_t vh_mono_scratch_bytes(int32_t n_sets, int64_t cap);
+int64_t vh_mono_scratch_bytes(int32_t n_sets, int64_t cap, int32_t ransac_iters);
 void vh_launch_mono(const vh_mono_params &e, int32_t n_sets, const vh_p_match *pm, int64_t pm_stride, const int32_t *offsets,
                     const int32_t *counts, int32_t count_cap, const int32_t *rand8, uint8_t *scratch, int64_t cap, double *tr,
                     int32_t *ok, int32_t *ninl, int32_t *inl, int64_t inl_stride, hipStream_t st);

@@ -36,14 +36,64 @@ template <int M, int N> int run(int trials, unsigned seed) {
       for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) U3[i][j] = a[i * N + j];
       svd_static_last_v<M, N>(U3, w3, V3, lv);
       for (int i = 0; i < N && ok; i++) if (memcmp(&lv[i], &Vr[i * N + N - 1], 8)) ok = false;
+      // ... and the one without U and without the sign normalisation: the same column up to sign, the same w
+      double U4[M][N], w4[N], V4[N][N], lu[N];
+      for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) U4[i][j] = a[i * N + j];
+      svd_static_last_v_unsigned<M, N>(U4, w4, V4, lu);
+      bool same = true, opposite = true;
+      for (int i = 0; i < N; i++) { const double neg = -lv[i]; same = same && !memcmp(&lu[i], &lv[i], 8); opposite = opposite && !memcmp(&lu[i], &neg, 8); }
+      if (!same && !opposite) ok = false;
+      for (int j = 0; j < N && ok; j++) if (memcmp(&w4[j], &w3[j], 8)) ok = false;
     }
     if (!ok) { bad++; if (bad < 4) printf("  mismatch M=%d N=%d trial %d (kind %d)\n", M, N, t, t % 5); }
   }
   printf("svd_static<%d,%d>: %d trials, %d mismatching\n", M, N, trials, bad);
   return bad;
 }
+// The mirror-image property fundamental8<false> rests on (csrc/kernels_mono.hip): the rank-2 projection
+// U diag(w0, w1, 0) V^T of -F is exactly minus that of F -- unless svd_static reports a zero Householder pivot.
+static bool rank2(const double *m, double *out) {
+  double U[3][3], w[3], V[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i][j] = m[i * 3 + j];
+  const bool zp = svd_static<3, 3>(U, w, V);
+  const double d[3] = {w[0], w[1], 0.0};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double ud[3], acc = 0.0;
+    for (int k = 0; k < 3; k++) { ud[k] = 0.0; for (int q = 0; q < 3; q++) ud[k] += U[i][q] * (q == k ? d[k] : 0.0); }
+    for (int k = 0; k < 3; k++) acc += ud[k] * V[j][k];
+    out[i * 3 + j] = acc;
+  }
+  return zp;
+}
+static int mirror(int trials, unsigned seed) {
+  std::mt19937 rng(seed); std::normal_distribution<double> nd;
+  int bad = 0, flagged = 0, broken_flagged = 0, per_kind[6] = {0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < trials; t++) {
+    double m[9], n[9], a[9], b[9];
+    for (auto &x : m) x = nd(rng);
+    if (t % 6 == 1) for (auto &x : m) x = std::round(x);              // exact zeros among the entries, often singular
+    if (t % 6 == 2) { m[0] = 0; m[4] = 0; m[8] = 0; }                 // skew-like: zero diagonal
+    if (t % 6 == 3) { m[t % 9] = 0; m[(t / 9) % 9] = -0.0; }
+    if (t % 6 == 4) { double p[3], q[3], r[3], s[3]; for (int i = 0; i < 3; i++) { p[i] = nd(rng); q[i] = nd(rng); r[i] = nd(rng); s[i] = nd(rng); }
+                      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i * 3 + j] = p[i] * q[j] + r[i] * s[j]; }   // rank 2 up to rounding (a noise-free F)
+    if (t % 6 == 5) { double p[3], q[3]; for (int i = 0; i < 3; i++) { p[i] = std::round(nd(rng) * 3); q[i] = nd(rng); }
+                      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i * 3 + j] = p[i] * q[j]; }                 // rank 1
+    for (int i = 0; i < 9; i++) n[i] = -m[i];
+    const bool za = rank2(m, a), zb = rank2(n, b);
+    bool mirror_ok = true;
+    for (int i = 0; i < 9; i++) { const double neg = -a[i]; if (memcmp(&neg, &b[i], 8) && !(a[i] == 0.0 && b[i] == 0.0)) mirror_ok = false; }
+    if (za != zb) { bad++; if (bad < 4) printf("  zero-pivot flag differs between F and -F, trial %d\n", t); }
+    flagged += za ? 1 : 0; per_kind[t % 6] += za ? 1 : 0;
+    if (!mirror_ok) { if (za) broken_flagged++; else { bad++; if (bad < 4) printf("  mirror image broken without a flag, trial %d\n", t); } }
+  }
+  printf("rank-2 mirror image: %d trials, %d flagged (%d of them really differ), %d unflagged failures\n", trials, flagged, broken_flagged, bad);
+  printf("  flagged per family (random, integer, zero diagonal, two zeros, rank 2, rank 1): %d %d %d %d %d %d of %d each\n", per_kind[0], per_kind[1], per_kind[2],
+         per_kind[3], per_kind[4], per_kind[5], trials / 6);
+  if (per_kind[0]) { printf("  a generic matrix was flagged\n"); bad++; }
+  return bad;
+}
 int main() {
-  int bad = 0;
+  int bad = mirror(120000, 9);
   bad += run<8, 9>(1500, 1); bad += run<3, 3>(3000, 2); bad += run<4, 4>(3000, 3);
   return bad != 0;
 }
