@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1357,6 +1358,39 @@ int32_t vh_group_estimate_motion(vh_group *g, const vh_ego_params *e, const int3
   Group *gq = (Group *)g; ENTER(gq);
   return gq->estimate_motion(e, rand3, tr, ok, n_inliers);
 }
+// Device work buffer of the stateless estimators: one per device, grow-only, kept between calls (an allocation and its
+// release cost more than the kernels of a bucketed batch).  Requests above 1 GiB are not kept.  The lock is held for the
+// whole call: stateless estimates on one device run one at a time.
+struct EgoWork {
+  std::mutex mu;
+  uint8_t *buf[16] = {};
+  size_t bytes[16] = {};
+};
+static EgoWork g_ego_work;
+struct EgoWorkLease {
+  std::unique_lock<std::mutex> lock;
+  uint8_t *d = nullptr;
+  bool kept = false;
+  hipError_t take(int32_t device, size_t need) {
+    lock = std::unique_lock<std::mutex>(g_ego_work.mu);
+    if (device >= 0 && device < 16 && need <= ((size_t)1 << 30)) {
+      kept = true;
+      if (g_ego_work.bytes[device] < need) {
+        if (g_ego_work.buf[device]) (void)hipFree(g_ego_work.buf[device]);
+        g_ego_work.buf[device] = nullptr; g_ego_work.bytes[device] = 0;
+        const size_t want = need + need / 4;
+        const hipError_t er = hipMalloc((void **)&g_ego_work.buf[device], want);
+        if (er != hipSuccess) return er;
+        g_ego_work.bytes[device] = want;
+      }
+      d = g_ego_work.buf[device];
+      return hipSuccess;
+    }
+    return hipMalloc((void **)&d, need);
+  }
+  ~EgoWorkLease() { if (d && !kept) (void)hipFree(d); }
+};
+
 int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_t n_sets, const vh_p_match *pm,
                                   const int32_t *offsets, const int32_t *rand3, double *tr, int32_t *ok,
                                   int32_t *n_inliers, int32_t *inliers) {
@@ -1379,7 +1413,9 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
   const size_t b_tr = sizeof(double) * 6 * (size_t)n_sets, b_xyz = sizeof(double) * 4 * (size_t)n_sets * (size_t)std::max<int64_t>(nmax, 1);
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t o_off = up(b_pm), o_r = o_off + up(b_off), o_ok = o_r + up(b_r), o_inl = o_ok + up(b_ok), o_tr = o_inl + up(b_inl), o_xyz = o_tr + up(b_tr);
-  VH_HIP(hipMalloc((void **)&d, o_xyz + b_xyz));
+  EgoWorkLease lease;
+  VH_HIP(lease.take(device, o_xyz + b_xyz));
+  d = lease.d;
   hipError_t er = hipSuccess;
   if (total) er = hipMemcpy(d, pm, sizeof(vh_p_match) * (size_t)total, hipMemcpyHostToDevice);
   if (er == hipSuccess) er = hipMemcpy(d + o_off, offsets, b_off, hipMemcpyHostToDevice);
@@ -1394,7 +1430,6 @@ int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_
   if (er == hipSuccess) er = hipMemcpy(ok, d + o_ok, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
   if (er == hipSuccess) er = hipMemcpy(n_inliers, d + o_ok + sizeof(int32_t) * (size_t)n_sets, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
   if (er == hipSuccess && inliers && total) er = hipMemcpy(inliers, d + o_inl, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
   if (er != hipSuccess) { t_last_error = hipGetErrorString(er); return VH_ERR_HIP; }
   return VH_OK;
 }
@@ -1446,7 +1481,9 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
   const size_t b_tr = sizeof(double) * 6 * (size_t)n_sets, b_scr = (size_t)vh_mono_scratch_bytes(n_sets, cap, e->ransac_iters);
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t o_off = up(b_pm), o_r = o_off + up(b_off), o_ok = o_r + up(b_r), o_inl = o_ok + up(b_ok), o_tr = o_inl + up(b_inl), o_scr = o_tr + up(b_tr);
-  VH_HIP(hipMalloc((void **)&d, o_scr + b_scr));
+  EgoWorkLease lease;
+  VH_HIP(lease.take(device, o_scr + b_scr));
+  d = lease.d;
   hipError_t er = hipSuccess;
   if (total) er = hipMemcpy(d, pm, sizeof(vh_p_match) * (size_t)total, hipMemcpyHostToDevice);
   if (er == hipSuccess) er = hipMemcpy(d + o_off, offsets, b_off, hipMemcpyHostToDevice);
@@ -1460,7 +1497,6 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
   if (er == hipSuccess) er = hipMemcpy(ok, d + o_ok, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
   if (er == hipSuccess) er = hipMemcpy(n_inliers, d + o_ok + sizeof(int32_t) * (size_t)n_sets, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);
   if (er == hipSuccess && inliers && total) er = hipMemcpy(inliers, d + o_inl, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
   if (er != hipSuccess) { t_last_error = hipGetErrorString(er); return VH_ERR_HIP; }
   return VH_OK;
 }

@@ -21,7 +21,7 @@ for n in (400, 2000):
     for _ in range(3):
         tr, ok, inl = pkg.estimate_motion_mono(mono, lists, raw)
     dt = (time.perf_counter() - t0) / 3
-    print(f"vh_estimate_motion_mono: {S} lists x {n} matches x {mono.ransac_iters} hypotheses, upload + 3 kernels + download: "
+    print(f"vh_estimate_motion_mono: {S} lists x {n} matches x {mono.ransac_iters} hypotheses, upload + 6 kernels + download: "
           f"{1e3 * dt:.2f} ms per call ({1e6 * dt / S:.1f} us per list), ok {int(ok.sum())}/{S}, inliers {int(np.mean([len(i) for i in inl]))}", flush=True)
 W, H = 1241, 376
 dims = [W, H, pkg.synth.bytes_per_line(W)]
