@@ -99,40 +99,74 @@ __device__ __forceinline__ void ego_accumulate(const vh_ego_params &e, const Ego
 
 // Matrix::solve for the 6x6 system (src/matrix.cpp:417-504): Gauss-Jordan with full pivoting,
 // singular below 1e-20.  acc as produced by ego_accumulate; on success b = the solution.
+// Every array index is a compile-time constant after unrolling -- the pivot's row and column (data-dependent in
+// the original) select among the six rows / columns by predicates -- so the system lives in registers: with
+// dynamic indices it sat in private memory, and the 22 dependent solves of a hypothesis were 85 % of the
+// kernel (1.2 of 1.4 ms per batch of bucketed lists, tools/ego_phases.py).  The arithmetic applied to the
+// elements, and its order, are the original's.
 __device__ bool ego_solve(const double acc[27], double b[6]) {
   double A[6][6];
   {
     int32_t k = 0;
+#pragma unroll
     for (int32_t m = 0; m < 6; m++)
+#pragma unroll
       for (int32_t n = m; n < 6; n++) { A[m][n] = acc[k]; A[n][m] = acc[k]; k++; }
+#pragma unroll
     for (int32_t m = 0; m < 6; m++) b[m] = acc[21 + m];
   }
   int32_t ipiv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
   for (int32_t i = 0; i < 6; i++) {
     double big = 0.0;
     int32_t irow = 0, icol = 0;
+#pragma unroll
     for (int32_t j = 0; j < 6; j++)
-      if (ipiv[j] != 1)
-        for (int32_t k = 0; k < 6; k++)
-          if (ipiv[k] == 0)
-            if (fabs(A[j][k]) >= big) { big = fabs(A[j][k]); irow = j; icol = k; }
-    ++ipiv[icol];
-    if (irow != icol) {
-      for (int32_t l = 0; l < 6; l++) { const double t = A[irow][l]; A[irow][l] = A[icol][l]; A[icol][l] = t; }
-      const double t = b[irow]; b[irow] = b[icol]; b[icol] = t;
-    }
-    if (fabs(A[icol][icol]) < 1e-20) return false;
-    const double pivinv = 1.0 / A[icol][icol];
-    A[icol][icol] = 1.0;
-    for (int32_t l = 0; l < 6; l++) A[icol][l] *= pivinv;
-    b[icol] *= pivinv;
-    for (int32_t ll = 0; ll < 6; ll++)
-      if (ll != icol) {
-        const double dum = A[ll][icol];
-        A[ll][icol] = 0.0;
-        for (int32_t l = 0; l < 6; l++) A[ll][l] -= A[icol][l] * dum;
-        b[ll] -= b[icol] * dum;
+#pragma unroll
+      for (int32_t k = 0; k < 6; k++) {
+        const double v = fabs(A[j][k]);
+        if (ipiv[j] != 1 && ipiv[k] == 0 && v >= big) { big = v; irow = j; icol = k; }
       }
+#pragma unroll
+    for (int32_t q = 0; q < 6; q++) ipiv[q] += q == icol ? 1 : 0;
+    // rows irow and icol change places (nothing moves when they are the same row)
+    double ri[6], rc[6], bi = 0.0, bc = 0.0;
+#pragma unroll
+    for (int32_t l = 0; l < 6; l++) { ri[l] = 0.0; rc[l] = 0.0; }
+#pragma unroll
+    for (int32_t r = 0; r < 6; r++) {
+#pragma unroll
+      for (int32_t l = 0; l < 6; l++) { ri[l] = r == irow ? A[r][l] : ri[l]; rc[l] = r == icol ? A[r][l] : rc[l]; }
+      bi = r == irow ? b[r] : bi; bc = r == icol ? b[r] : bc;
+    }
+#pragma unroll
+    for (int32_t r = 0; r < 6; r++) {
+#pragma unroll
+      for (int32_t l = 0; l < 6; l++) A[r][l] = r == icol ? ri[l] : (r == irow ? rc[l] : A[r][l]);
+      b[r] = r == icol ? bi : (r == irow ? bc : b[r]);
+    }
+    // the pivot row (now row icol) is ri, its right-hand side bi
+    double piv = 0.0;
+#pragma unroll
+    for (int32_t l = 0; l < 6; l++) piv = l == icol ? ri[l] : piv;
+    if (fabs(piv) < 1e-20) return false;
+    const double pivinv = 1.0 / piv;
+#pragma unroll
+    for (int32_t l = 0; l < 6; l++) ri[l] = (l == icol ? 1.0 : ri[l]) * pivinv;
+    bi *= pivinv;
+#pragma unroll
+    for (int32_t ll = 0; ll < 6; ll++) {
+      double dum = 0.0;
+#pragma unroll
+      for (int32_t l = 0; l < 6; l++) dum = l == icol ? A[ll][l] : dum;
+      const bool prow = ll == icol;
+#pragma unroll
+      for (int32_t l = 0; l < 6; l++) {
+        const double cur = l == icol ? 0.0 : A[ll][l];
+        A[ll][l] = prow ? ri[l] : cur - ri[l] * dum;
+      }
+      b[ll] = prow ? bi : b[ll] - bi * dum;
+    }
   }
   return true;
 }
@@ -154,6 +188,16 @@ __device__ __forceinline__ bool ego_is_inlier(const vh_ego_params &e, const EgoR
 
 #define EGO_T 256
 
+// -DVH_EGO_TIMING: workgroup 0 adds the 100 MHz clock ticks of its phases to g_ego_t (tools/ego_phases.py)
+__device__ unsigned long long g_ego_t[8];
+#ifdef VH_EGO_TIMING
+#define VH_ETK_INIT unsigned long long et_prev_ = wall_clock64()
+#define VH_ETK(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_ego_t[k], now_ - et_prev_); et_prev_ = now_; } } while (0)
+#else
+#define VH_ETK_INIT do { } while (0)
+#define VH_ETK(k) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(EGO_T)
 ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_stride, const int32_t *__restrict__ offsets,
            const int32_t *__restrict__ counts, int32_t count_cap, const int32_t *__restrict__ rand3, double *__restrict__ xyz,
@@ -173,6 +217,7 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
     if (tid == 0) { ok_out[s] = 0; ninl_out[s] = 0; for (int32_t m = 0; m < 6; m++) tr_out[6 * s + m] = 0; }
     return;
   }
+  VH_ETK_INIT;
   // 1. project the matches of the previous image into 3d (src/viso_stereo.cpp:80-85)
   for (int32_t i = tid; i < n; i += EGO_T) {
     const float df = pm[i].u1p - pm[i].u2p;
@@ -183,6 +228,7 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
   }
   if (tid == 0) sBestKey = 0;
   __syncthreads();
+  VH_ETK(0);  // 3-d points
 
   // 2. hypotheses: one per thread
   for (int32_t k0 = 0; k0 < e.ransac_iters; k0 += EGO_T) {
@@ -216,6 +262,9 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
         for (int32_t m = 0; m < 6; m++) { t6[m] += bsol[m]; if (fabs(bsol[m]) > 1e-6) converged = false; }
         if (iter++ > 20 || converged) break;
       }
+#ifdef VH_EGO_TIMING
+      if (blockIdx.x == 0 && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_ego_t[1], now_ - et_prev_); et_prev_ = now_; }  // Gauss-Newton on the sample (wave 0's)
+#endif
       if (!failed) {  // its inliers over all matches (src/viso_stereo.cpp:113-119)
         EgoRot R;
         ego_rot(t6, R);
@@ -238,6 +287,7 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
     if (key && key == sBestKey) for (int32_t m = 0; m < 6; m++) sTr[m] = t6[m];  // unique: the hypothesis number is part of the key
     __syncthreads();
   }
+  VH_ETK(2);  // inlier counts + arg max
   const int32_t nbest = (int32_t)(sBestKey >> 32);
   // ordered inlier list of the winner (VisualOdometry::inliers)
   double tr[6];
@@ -263,6 +313,7 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
       __syncthreads();
     }
   }
+  VH_ETK(3);  // inlier list
   // 4. final optimisation on the inliers (src/viso_stereo.cpp:123-139)
   bool success = nbest >= 6;
   if (success) {
@@ -303,6 +354,7 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
       if (iter++ > 100) { success = false; break; }              // still UPDATED after 102 updates
     }
   }
+  VH_ETK(4);  // refit
   if (tid == 0) {
     ok_out[s] = success ? 1 : 0;
     ninl_out[s] = nbest;
@@ -311,6 +363,12 @@ ego_kernel(vh_ego_params e, const vh_p_match *__restrict__ pm_base, int64_t pm_s
 }
 
 }  // namespace
+
+extern "C" int32_t vh_debug_ego_timing(unsigned long long *out, int32_t reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ego_t), sizeof(g_ego_t)) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ego_t), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
 
 void vh_launch_ego(const vh_ego_params &e, int32_t n_sets, const vh_p_match *pm, int64_t pm_stride, const int32_t *offsets,
                    const int32_t *counts, int32_t count_cap, const int32_t *rand3, double *xyz, int64_t xyz_stride, double *tr,
