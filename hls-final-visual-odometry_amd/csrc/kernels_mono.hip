@@ -266,7 +266,7 @@ __device__ void transpose3(const double *A, double *T) {
 // Matrix::svd of a 3x3 followed by U * diag(W with W[2] = 0) * ~V (src/viso_mono.cpp:262-265, :91-94).
 // The factors live in registers (svd_static.h: every index static after unrolling).
 // (returns svd_static's zero-pivot flag, see fundamental8)
-__device__ bool rank2_3x3(const double *M, double *out) {
+__device__ __forceinline__ bool rank2_3x3(const double *M, double *out) {
   double U[3][3], w[3], V[3][3], a[9], D[9], UD[9], Vt[9];
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -485,8 +485,8 @@ mono_norm_kernel(const vh_p_match *__restrict__ pm_base, int64_t pm_stride, cons
 //   not be (a Householder pivot that is exactly zero) is reported through the return value, and the caller then
 //   takes the signed form.
 template <bool SIGNED>
-__device__ bool fundamental8(const float4 *pn, const int32_t *act, double *F) {
-  double Ur[8][9], wr[9], Vr[9][9], F0[9];
+__device__ __forceinline__ bool fundamental8(const float4 *pn, const int32_t *act, double *F, double (&F0)[9]) {
+  double Ur[8][9], wr[9], Vr[9][9];
 #pragma unroll
   for (int32_t i = 0; i < 8; i++) {
     const float4 q = pn[act[i]];  // (u1p, v1p, u1c, v1c)
@@ -548,8 +548,9 @@ __device__ __forceinline__ int32_t sampson_settle(int32_t r, double n, double de
 
 // ------------------------------------------------------------------- mono_hyp
 // One lane per hypothesis.  The SIGNED = false launch does the work; a hypothesis that meets the mirror-image hazard
-// of fundamental8 (a numerically singular 3x3: noise-free scenes have them, image data hardly ever) does not vote there
-// but is queued, and the SIGNED = true launch behind it counts the queued ones the reference's way into the same key.
+// of fundamental8 (a numerically singular 3x3: noise-free scenes have them, image data hardly ever) AND whose two
+// candidate matrices disagree on a match does not vote there but is queued, and the SIGNED = true launch behind it
+// counts the queued ones the reference's way into the same key.
 // force_signed (VH_MONO_SIGNED=1, the tests): every hypothesis takes the second launch.
 template <bool SIGNED>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SIGNED ? 1 : 2, SIGNED ? 1 : 2)))  // (the fast form fits 256 registers: two waves per SIMD)
@@ -567,13 +568,51 @@ mono_hyp_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_
     s = blockIdx.y; k = blockIdx.x * 128 + threadIdx.x;
   }
   const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
-  if (L.hdr[18] == 0.0 || k >= e.ransac_iters) return;
+  // (no lane leaves before the cooperative check below: a wave's lanes are hypotheses of one list)
+  const bool valid = L.hdr[18] != 0.0 && k < e.ransac_iters;
+  if (SIGNED && !valid) return;
   int32_t act[8];
   double F[9];
+  const MonoPoint *__restrict__ pd = (const MonoPoint *)L.A;
+  const double thr = e.inlier_threshold;
   bool hazard = !SIGNED && force_signed != 0;
-  if (!hazard) {
+  if (SIGNED) {
+    double F0[9];
     sample8(rand8 + ((int64_t)s * e.ransac_iters + k) * 8, L.n, act);
-    hazard = fundamental8<SIGNED>(L.pn, act, F);
+    fundamental8<true>(L.pn, act, F, F0);
+  } else {
+    // A hypothesis that raised fundamental8's flag: the reference's F is the rank-2 projection of +F0 or of -F0 -- which
+    // one, only U knows.  Both are at hand: when they agree on every match (they differ, if at all, in the last bits)
+    // the sign does not matter and the hypothesis is counted here after all; otherwise it goes to the signed kernel.
+    // The comparison is made by the whole wave, lanes over matches, for one flagged lane after the other: on its own
+    // lane it would double that lane's loop over the matches and with it the duration of its wave.
+    double Fm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool flagged = false;
+    if (valid && !hazard) {
+      double F0[9];
+      sample8(rand8 + ((int64_t)s * e.ransac_iters + k) * 8, L.n, act);
+      flagged = fundamental8<false>(L.pn, act, F, F0);
+      if (flagged) {
+#pragma unroll
+        for (int32_t q = 0; q < 9; q++) F0[q] = -F0[q];
+        rank2_3x3(F0, Fm);
+      }
+    }
+    const int32_t lane = threadIdx.x & 63;
+    for (uint64_t todo = __ballot(flagged); todo; todo &= todo - 1) {
+      const int32_t j = __ffsll((unsigned long long)todo) - 1;
+      double Fa[9], Fb[9];
+#pragma unroll
+      for (int32_t q = 0; q < 9; q++) { Fa[q] = __shfl(F[q], j); Fb[q] = __shfl(Fm[q], j); }
+      int32_t differ = 0;
+      for (int32_t i = lane; i < L.n; i += 64) {
+        double n1, d1, n2, d2;
+        differ |= sampson_settle(sampson_inlier_nodiv(Fa, pd[i], thr, n1, d1), n1, d1, thr) ^ sampson_settle(sampson_inlier_nodiv(Fb, pd[i], thr, n2, d2), n2, d2, thr);
+      }
+      const bool any = __ballot(differ != 0) != 0;
+      if (lane == j) hazard = any;
+    }
+    if (!valid) return;
   }
   if (hazard) { queue[4 + atomicAdd(queue, 1u)] = (uint32_t)s * (uint32_t)e.ransac_iters + (uint32_t)k; return; }
   {
@@ -582,8 +621,6 @@ mono_hyp_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, int64_
     for (int32_t q = 0; q < 9; q++) Fk[q] = F[q];
   }
   int32_t cnt = 0;
-  const MonoPoint *__restrict__ pd = (const MonoPoint *)L.A;
-  const double thr = e.inlier_threshold;
   int32_t i = 0;
   for (; i + 4 <= L.n; i += 4) {  // four independent chains per trip
     double n4[4], d4[4];
