@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "vh_group_profile_read", "vh_group_profile_reset",
     "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion", "vh_group_search_stats",
     "vh_default_mono_params", "vh_estimate_motion_mono", "vh_group_estimate_motion_mono",
-    "vh_group_post_begin", "vh_group_post_finish",
+    "vh_group_post_begin", "vh_group_post_finish", "vh_group_post_finish_mono",
 )
 
 
@@ -172,6 +172,7 @@ def _lib():
             "vh_group_estimate_motion_mono": [vp, vp, vp, vp, vp, vp],
             "vh_group_post_begin": [vp, i32],
             "vh_group_post_finish": [vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp],
+            "vh_group_post_finish_mono": [vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp],
             "vh_group_search_stats": [vp, vp, vp],
         }
         for name, args in sig.items():
@@ -448,9 +449,10 @@ class StreamGroup:
         _check(_lib().vh_group_post_begin(self._h, int(cap_per_stream)), "vh_group_post_begin")
 
     def postFinish(self, age: int, max_features: int, bucket_width: float, bucket_height: float, host_threads: int = 0,
-                   ego: "EgoParams" = None, rand3=None, want_lists: bool = True, list_cap: int = 0):
-        """removeOutliers + bucketFeatures (+ estimateMotion when `ego` is given) of the step begun `age` begins ago
-        (vh_group_post_finish) -> dict(tr, ok, n_inliers, lists, host_ms)."""
+                   ego: "EgoParams" = None, rand3=None, want_lists: bool = True, list_cap: int = 0, mono: "MonoParams" = None, rand8=None):
+        """removeOutliers + bucketFeatures (+ the stereo estimateMotion when `ego` is given, the monocular one when
+        `mono` is) of the step begun `age` begins ago (vh_group_post_finish / vh_group_post_finish_mono)
+        -> dict(tr, ok, n_inliers, lists, host_ms)."""
         S = self.S
         tr = np.zeros((S, 6), np.float64); ok = np.zeros(S, np.int32); ninl = np.zeros(S, np.int32)
         counts = np.zeros(S, np.int32); ms = C.c_double(0.0)
@@ -462,9 +464,17 @@ class StreamGroup:
         if ego is not None:
             r3 = np.ascontiguousarray(rand3, np.int32)
             assert r3.shape == (S, ego.ransac_iters, 3)
-        _check(_lib().vh_group_post_finish(self._h, int(age), int(max_features), C.c_float(bucket_width), C.c_float(bucket_height),
-                                           int(host_threads), C.byref(ego) if ego is not None else None, _ptr(r3), _ptr(tr), _ptr(ok),
-                                           _ptr(ninl), _ptr(out), int(list_cap), _ptr(counts), C.byref(ms)), "vh_group_post_finish")
+        if mono is not None:
+            assert ego is None
+            r8 = np.ascontiguousarray(rand8, np.int32)
+            assert r8.shape == (S, mono.ransac_iters, 8)
+            _check(_lib().vh_group_post_finish_mono(self._h, int(age), int(max_features), C.c_float(bucket_width), C.c_float(bucket_height),
+                                                    int(host_threads), C.byref(mono), _ptr(r8), _ptr(tr), _ptr(ok),
+                                                    _ptr(ninl), _ptr(out), int(list_cap), _ptr(counts), C.byref(ms)), "vh_group_post_finish_mono")
+        else:
+            _check(_lib().vh_group_post_finish(self._h, int(age), int(max_features), C.c_float(bucket_width), C.c_float(bucket_height),
+                                               int(host_threads), C.byref(ego) if ego is not None else None, _ptr(r3), _ptr(tr), _ptr(ok),
+                                               _ptr(ninl), _ptr(out), int(list_cap), _ptr(counts), C.byref(ms)), "vh_group_post_finish")
         lists = [out[s, :counts[s]].copy() for s in range(S)] if want_lists else None
         return {"tr": tr, "ok": ok.astype(bool), "n_inliers": ninl, "lists": lists, "counts": counts, "host_ms": ms.value}
 

@@ -207,7 +207,7 @@ struct Group {
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
     d_ego_rand = nullptr; d_ego_ok = nullptr; d_ego_xyz = nullptr; d_ego_tr = nullptr; ego_rand_n = 0;
     d_mono_scratch = nullptr; d_mono_rand = nullptr; mono_rand_n = 0; mono_scratch_iters = 0;
-    d_bucket = nullptr; d_bcnt = nullptr; bcap = 0; d_post_rand = nullptr; post_rand_n = 0; d_post_xyz = nullptr; d_post_tr = nullptr; d_post_ok = nullptr;
+    d_bucket = nullptr; d_bcnt = nullptr; bcap = 0; d_post_rand = nullptr; post_rand_n = 0; d_post_mono = nullptr; post_mono_iters = 0; d_post_xyz = nullptr; d_post_tr = nullptr; d_post_ok = nullptr;
     if (h_bucket) { (void)hipHostFree(h_bucket); h_bucket = nullptr; }
     if (h_bcnt) { (void)hipHostFree(h_bcnt); h_bcnt = nullptr; }
     for (auto &sl : post_slot) {
@@ -848,6 +848,7 @@ struct Group {
   vh_p_match *h_bucket = nullptr, *d_bucket = nullptr;  // [S][bcap]
   int32_t *h_bcnt = nullptr, *d_bcnt = nullptr, bcap = 0;
   int32_t *d_post_rand = nullptr; size_t post_rand_n = 0;
+  uint8_t *d_post_mono = nullptr; int32_t post_mono_iters = 0;
   double *d_post_xyz = nullptr, *d_post_tr = nullptr; int32_t *d_post_ok = nullptr;
 
   int32_t post_begin(int32_t cap_ps) {
@@ -876,10 +877,13 @@ struct Group {
     return VH_OK;
   }
 
+  // (e: the stereo estimator with rand3, or mono: the monocular one with rand8 -- at most one of them)
   int32_t post_finish(int32_t age, int32_t max_features, float bw, float bh, int32_t threads, const vh_ego_params *e, const int32_t *rand3,
+                      const vh_mono_params *mono, const int32_t *rand8,
                       double *tr, int32_t *ok, int32_t *ninl, vh_p_match *out, int32_t out_cap, int32_t *out_counts, double *host_ms) {
-    if (age < 0 || age > 1 || max_features < 1 || !(bw > 0) || !(bh > 0) || threads < 1) return VH_ERR_INVALID_ARG;
+    if (age < 0 || age > 1 || max_features < 1 || !(bw > 0) || !(bh > 0) || threads < 1 || (e && mono)) return VH_ERR_INVALID_ARG;
     if (e && (!rand3 || !tr || !ok || !ninl || e->ransac_iters < 1)) return VH_ERR_INVALID_ARG;
+    if (mono && (!rand8 || !tr || !ok || !ninl || mono->ransac_iters < 1 || (int64_t)S * mono->ransac_iters > (int64_t)1 << 31)) return VH_ERR_INVALID_ARG;
     if (post_seq - 1 - age < 0) return VH_ERR_STATE;
     PostSlot &sl = post_slot[(post_seq - 1 - age) & 1];
     if (!sl.pending) return VH_ERR_STATE;
@@ -900,6 +904,7 @@ struct Group {
       if ((rc = dmalloc(&d_post_xyz, (size_t)S * need * 4, false))) return rc;
       if (!d_post_tr) { if ((rc = dmalloc(&d_post_tr, 6 * (size_t)S, false))) return rc; if ((rc = dmalloc(&d_post_ok, 2 * (size_t)S, false))) return rc; }
       bcap = (int32_t)need;
+      post_mono_iters = 0;  // (the monocular scratch is sized by bcap as well)
     }
     const auto t0 = std::chrono::steady_clock::now();
     std::atomic<int32_t> next_stream(0), failed(0);
@@ -930,15 +935,22 @@ struct Group {
         memcpy(out + (size_t)s * out_cap, h_bucket + (size_t)s * bcap, sizeof(vh_p_match) * (size_t)h_bcnt[s]);
       }
     }
-    if (!e) return VH_OK;
-    if (sl.method != VH_METHOD_QUAD) return VH_ERR_STATE;  // the stereo estimator needs both cameras of both frames
-    const size_t nr = (size_t)S * e->ransac_iters * 3;
+    if (!e && !mono) return VH_OK;
+    if (e && sl.method != VH_METHOD_QUAD) return VH_ERR_STATE;  // the stereo estimator needs both cameras of both frames
+    if (mono && sl.method == VH_METHOD_STEREO) return VH_ERR_STATE;  // the monocular one the left camera of both frames
+    const size_t nr = e ? (size_t)S * e->ransac_iters * 3 : (size_t)S * mono->ransac_iters * 8;
     if (post_rand_n < nr) { int32_t rc = dmalloc(&d_post_rand, nr, false); if (rc) return rc; post_rand_n = nr; }
+    if (mono && post_mono_iters < mono->ransac_iters) {
+      int32_t rc = dmalloc(&d_post_mono, (size_t)vh_mono_scratch_bytes(S, bcap, mono->ransac_iters), false);
+      if (rc) return rc;
+      post_mono_iters = mono->ransac_iters;
+    }
     // the bucketed lists go up as one block; everything on the download stream, beside the next step's kernels
     VH_HIP(hipMemcpyAsync(d_bucket, h_bucket, sizeof(vh_p_match) * (size_t)S * bcap, hipMemcpyHostToDevice, down_stream));
     VH_HIP(hipMemcpyAsync(d_bcnt, h_bcnt, sizeof(int32_t) * (size_t)S, hipMemcpyHostToDevice, down_stream));
-    VH_HIP(hipMemcpyAsync(d_post_rand, rand3, sizeof(int32_t) * nr, hipMemcpyHostToDevice, down_stream));
-    vh_launch_ego(*e, S, d_bucket, bcap, nullptr, d_bcnt, bcap, d_post_rand, d_post_xyz, bcap, d_post_tr, d_post_ok, d_post_ok + S, nullptr, 0, down_stream);
+    VH_HIP(hipMemcpyAsync(d_post_rand, e ? rand3 : rand8, sizeof(int32_t) * nr, hipMemcpyHostToDevice, down_stream));
+    if (e) vh_launch_ego(*e, S, d_bucket, bcap, nullptr, d_bcnt, bcap, d_post_rand, d_post_xyz, bcap, d_post_tr, d_post_ok, d_post_ok + S, nullptr, 0, down_stream);
+    else vh_launch_mono(*mono, S, d_bucket, bcap, nullptr, d_bcnt, bcap, d_post_rand, d_post_mono, bcap, d_post_tr, d_post_ok, d_post_ok + S, nullptr, 0, down_stream);
     VH_HIP(hipGetLastError());
     VH_HIP(hipMemcpyAsync(tr, d_post_tr, sizeof(double) * 6 * (size_t)S, hipMemcpyDeviceToHost, down_stream));
     VH_HIP(hipMemcpyAsync(ok, d_post_ok, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, down_stream));
@@ -1443,7 +1455,14 @@ int32_t vh_group_post_finish(vh_group *g, int32_t age, int32_t max_features, flo
                              vh_p_match *bucketed, int32_t cap_per_stream, int32_t *counts, double *host_ms) {
   Group *gq = (Group *)g; ENTER(gq);
   if (host_threads < 1) host_threads = (int32_t)std::max(1u, std::thread::hardware_concurrency());
-  return gq->post_finish(age, max_features, bucket_width, bucket_height, host_threads, e, rand3, tr, ok, n_inliers, bucketed, cap_per_stream, counts, host_ms);
+  return gq->post_finish(age, max_features, bucket_width, bucket_height, host_threads, e, rand3, nullptr, nullptr, tr, ok, n_inliers, bucketed, cap_per_stream, counts, host_ms);
+}
+int32_t vh_group_post_finish_mono(vh_group *g, int32_t age, int32_t max_features, float bucket_width, float bucket_height, int32_t host_threads,
+                                  const vh_mono_params *e, const int32_t *rand8, double *tr, int32_t *ok, int32_t *n_inliers,
+                                  vh_p_match *bucketed, int32_t cap_per_stream, int32_t *counts, double *host_ms) {
+  Group *gq = (Group *)g; ENTER(gq);
+  if (host_threads < 1) host_threads = (int32_t)std::max(1u, std::thread::hardware_concurrency());
+  return gq->post_finish(age, max_features, bucket_width, bucket_height, host_threads, nullptr, nullptr, e, rand8, tr, ok, n_inliers, bucketed, cap_per_stream, counts, host_ms);
 }
 
 // ---- monocular egomotion -----------------------------------------

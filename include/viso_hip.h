@@ -369,6 +369,14 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
  * (VH_METHOD_FLOW or VH_METHOD_QUAD: both carry the left camera's flow). */
 int32_t vh_group_estimate_motion_mono(vh_group *g, const vh_mono_params *e, const int32_t *rand8, double *tr,
                                       int32_t *ok, int32_t *n_inliers);
+/* vh_group_post_finish with the MONOCULAR estimator as its last stage: what VisualOdometryMono::process runs
+ * after the matching (src/viso_mono.cpp:34-37: bucketFeatures, then estimateMotion on the bucketed list; the
+ * Delaunay vote before them is the tail of matchFeatures) for every stream of a group, flow or quad lists,
+ * rand8[S][ransac_iters][8].  Everything else as vh_group_post_finish. */
+int32_t vh_group_post_finish_mono(vh_group *g, int32_t age, int32_t max_features, float bucket_width, float bucket_height,
+                                  int32_t host_threads, const vh_mono_params *e, const int32_t *rand8, double *tr,
+                                  int32_t *ok, int32_t *n_inliers, vh_p_match *bucketed, int32_t cap_per_stream,
+                                  int32_t *counts, double *host_ms);
 
 /* Which form of the search loops the group currently runs and the last observed share of
  * queries the speculative form had to search again (-1 before the first report).  The

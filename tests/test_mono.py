@@ -175,6 +175,47 @@ def test_gpu_group_estimate_motion_mono_on_device_matches(pkg, ob, oracle, gpu):
 
 
 @pytest.mark.gpu
+def test_gpu_pipelined_post_stage_with_the_mono_estimator(pkg, ob, oracle, gpu):
+    """vh_group_post_begin / vh_group_post_finish_mono -- VisualOdometryMono::process after the matching
+    (src/viso_mono.cpp:34-37) for a stream group: removeOutliers -> bucketFeatures(2, 50, 50) -> the monocular
+    estimateMotion of step t finished while step t+1 is already issued, per stream equal to the oracle's chain on the
+    same flow matches: bucketed lists bit for bit, success flags and inlier counts exact, tr to 1e-9."""
+    import ctypes as C
+    S, W, H, T = 3, 480, 200, 4
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, T, disparity=6 + s, blur=4, seed=410 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[oracle.compute_features(po, seqs[s][t][0], dims)[1] for t in range(T)] for s in range(S)]
+    e = ob.MonoParams.default(ransac_iters=300, height=1.65, f=400.0, cu=W / 2, cv=H / 2)
+    ge = _gpu_params(pkg, e)
+    raw = np.random.default_rng(4).integers(0, 2 ** 31 - 1, (T, S, 300, 8)).astype(np.int32)
+    g = pkg.StreamGroup(S, pkg.Params.default())
+
+    def check(t, got):
+        for s in range(S):
+            pm = oracle.matching(po, dims, 0, m1p=F[s][t - 1], m1c=F[s][t])
+            pm, _ = oracle.remove_outliers(pm)
+            q = pm.copy()
+            n = oracle.lib.vo_bucket_features(q.ctypes.data_as(C.c_void_p), len(q), 2, C.c_float(50), C.c_float(50))
+            q = q[:n].copy()
+            ok_o, tr_o, inl_o = oracle.estimate_motion_mono(e, q, oracle.draw_samples_n(len(q), 8, 300, raw[t, s].reshape(-1)))
+            assert len(q) > 20 and got["lists"][s].tobytes() == q.tobytes(), (t, s)
+            assert got["ok"][s] == ok_o and got["n_inliers"][s] == len(inl_o), (t, s)
+            assert _close(got["tr"][s], tr_o), (t, s, got["tr"][s], tr_o)
+
+    for t in range(T):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), None, dims, False)
+        if t == 0:
+            continue
+        g.matchFeatures(pkg.METHOD_FLOW)
+        g.postBegin(8192)
+        if t >= 2:  # step t is in flight on the GPU; finish step t-1
+            check(t - 1, g.postFinish(1, 2, 50.0, 50.0, host_threads=2, mono=ge, rand8=raw[t - 1]))
+    check(T - 1, g.postFinish(0, 2, 50.0, 50.0, host_threads=2, mono=ge, rand8=raw[T - 1]))
+    g.close()
+
+
+@pytest.mark.gpu
 def test_gpu_mono_signed_recount_path(gpu):
     """mono_hyp counts inliers with +-F (no U in the 8x9 decomposition) and hands a list to the signed kernel behind it
     when a hypothesis raises svd_static's mirror-image flag -- noise-free scenes do, image data does not.
@@ -182,7 +223,7 @@ def test_gpu_mono_signed_recount_path(gpu):
     GPU cases must pass on it."""
     import subprocess, sys
     env = dict(os.environ, VH_MONO_SIGNED="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "not signed_recount"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "not signed_recount and not pipelined"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
