@@ -213,6 +213,26 @@ def test_gpu_pipelined_post_stage_with_the_mono_estimator(pkg, ob, oracle, gpu):
             check(t - 1, g.postFinish(1, 2, 50.0, 50.0, host_threads=2, mono=ge, rand8=raw[t - 1]))
     check(T - 1, g.postFinish(0, 2, 50.0, 50.0, host_threads=2, mono=ge, rand8=raw[T - 1]))
     g.close()
+    # quad lists carry the left camera's flow as well (stereo lists do not: refused)
+    g = pkg.StreamGroup(1, pkg.Params.default())
+    Fq = [[oracle.compute_features(po, im, dims)[1] for im in seqs[0][t]] for t in range(2)]
+    for t in range(2):
+        g.pushBack(seqs[0][t][0][None], seqs[0][t][1][None], dims, False)
+    g.matchFeatures(pkg.METHOD_QUAD)
+    g.postBegin(8192)
+    got = g.postFinish(0, 2, 50.0, 50.0, host_threads=1, mono=ge, rand8=raw[0][:1])
+    pm, _ = oracle.remove_outliers(oracle.matching(po, dims, 2, Fq[0][0], Fq[0][1], Fq[1][0], Fq[1][1]))
+    q = pm.copy()
+    n = oracle.lib.vo_bucket_features(q.ctypes.data_as(C.c_void_p), len(q), 2, C.c_float(50), C.c_float(50))
+    q = q[:n].copy()
+    ok_o, tr_o, inl_o = oracle.estimate_motion_mono(e, q, oracle.draw_samples_n(len(q), 8, 300, raw[0, 0].reshape(-1)))
+    assert got["lists"][0].tobytes() == q.tobytes() and got["ok"][0] == ok_o and got["n_inliers"][0] == len(inl_o) and _close(got["tr"][0], tr_o)
+    g.matchFeatures(pkg.METHOD_STEREO)
+    g.postBegin(8192)
+    with pytest.raises(pkg.VisoHipError) as ex:
+        g.postFinish(0, 2, 50.0, 50.0, host_threads=1, mono=ge, rand8=raw[0][:1])
+    assert ex.value.code == pkg.VH_ERR_STATE
+    g.close()
 
 
 @pytest.mark.gpu
