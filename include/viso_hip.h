@@ -303,7 +303,10 @@ void vh_default_ego_params(vh_ego_params *e);
  * hypothesis at inliers[offsets[s] ..] (VisualOdometry::getInlierIndices).
  * Each hypothesis follows the reference's operation order exactly; the refinement sums the
  * normal equations in parallel, so tr agrees with the reference to rounding (1e-9 relative
- * is what tests/ assert), the inlier sets exactly. */
+ * is what tests/ assert), the inlier sets exactly.
+ * The two stateless estimators (this and vh_estimate_motion_mono) keep one device work buffer per
+ * device between calls (grow-only, requests above 1 GiB are not kept, released with the process)
+ * and run one at a time per process. */
 int32_t vh_estimate_motion_stereo(const vh_ego_params *e, int32_t device, int32_t n_sets, const vh_p_match *pm,
                                   const int32_t *offsets, const int32_t *rand3, double *tr, int32_t *ok,
                                   int32_t *n_inliers, int32_t *inliers);
