@@ -12,18 +12,24 @@
 // every inlier set -- is bit-identical to the reference's; only exp/sin/cos/asin come from the device
 // library (the ground-plane vote and the final angles agree to rounding).
 //
-// Three launches per batch (S lists):
-//   mono_norm   one workgroup per list: centroids and scales (sequential sums, one lane each -- the
-//               order of a floating-point sum is part of the result), normalised points as float4.
-//   mono_hyp    one THREAD per RANSAC hypothesis, grid (iters/128, S): 8-point system, Matrix::svd of
-//               the 8x9 and of the 3x3 matrix in private memory, rank-2 F, Sampson inlier count over
-//               all matches; arg max per list with one 64-bit atomicMax (count << 32 | 2^31-1-k: more
-//               inliers win, the earlier hypothesis on ties, as the reference's strict `>`).
-//   mono_final  one workgroup per list: ordered inlier list of the winner, F from all inliers (a
-//               workgroup-cooperative Matrix::svd of the N x 9 system: independent columns / rows on
-//               different lanes, every sum sequential), E, the four (R,t) candidates, triangulation of
-//               every match (one 4x4 SVD per lane), chirality vote, median distance, ground-plane
-//               vote, angles.
+// Six launches per batch (S lists; DESIGN.md section 6 has the measurements behind each choice):
+//   mono_norm     one workgroup per list: centroids and scales -- sequential sums (the order of a floating-point
+//                 sum is part of the result) over terms all lanes fetched into LDS; normalised points as float4
+//                 and, widened once, as doubles.
+//   mono_hyp<0>   one THREAD per RANSAC hypothesis, grid (iters/128, S): 8-point system, Matrix::svd of the 8x9
+//                 matrix in registers WITHOUT U (its null vector up to sign: svd_static.h), rank-2 F by a 3x3 SVD,
+//                 Sampson inlier count over all matches (quotient-free unless the answer is in doubt); arg max per
+//                 list with one 64-bit atomicMax (count << 32 | 2^31-1-k: more inliers win, the earlier
+//                 hypothesis on ties, as the reference's strict `>`); every hypothesis leaves its F in scratch.
+//                 A hypothesis whose +-F could differ in more than sign (flag of the 3x3 decomposition) has both
+//                 candidates compared by its wave; only if they disagree on a match is it queued for
+//   mono_hyp<1>   the same with U and the reference's sign, one lane per queued hypothesis (normally none).
+//   mono_final_a  one workgroup per list: ordered inlier list of the winner (its stored F), F from all inliers
+//                 (a workgroup-cooperative Matrix::svd of the N x 9 system: everything elementwise spread over the
+//                 lanes, every sum a sequential chain over terms formed beforehand), E, the four (R,t) candidates.
+//   mono_tri      one lane per (match, candidate): linear triangulation (4x4 SVD without U), chirality counts.
+//   mono_final_c  one workgroup per list: the winning candidate, points in front, median distance, ground-plane
+//                 vote, scale, angles.
 #include "vh_dev.h"
 #include "../../include/viso_hip.h"
 #include <math.h>
