@@ -150,113 +150,6 @@ __device__ __forceinline__ void svd_sort_phase(int n, double *w, Save save, Move
   } while (inc > 1);
 }
 
-// Matrix::svd (src/matrix.cpp:579-802) of a small m x n matrix held by ONE lane: a (row-major) is
-// replaced by the m x n factor U, w[n], v n x n; sorted, signs flipped.  tmp: n + max(m, n) + n doubles.
-__device__ void svd_lane(double *a, int m, int n, double *w, double *v, double *tmp) {
-  double *rv1 = tmp, *su = tmp + n, *sv = su + (m > n ? m : n);
-  int i, j, k, l = 0;
-  double anorm, f, g, h, s, scale;
-#define A(r, q) a[(r) * n + (q)]
-#define V(r, q) v[(r) * n + (q)]
-  for (i = 0; i < n * n; i++) v[i] = 0.0;
-  g = scale = anorm = 0.0;
-  for (i = 0; i < n; i++) {
-    l = i + 1;
-    rv1[i] = scale * g;
-    g = s = scale = 0.0;
-    if (i < m) {
-      for (k = i; k < m; k++) scale += fabs(A(k, i));
-      if (scale) {
-        for (k = i; k < m; k++) { A(k, i) /= scale; s += A(k, i) * A(k, i); }
-        f = A(i, i);
-        g = -sign_of(sqrt(s), f);
-        h = f * g - s;
-        A(i, i) = f - g;
-        for (j = l; j < n; j++) {
-          for (s = 0.0, k = i; k < m; k++) s += A(k, i) * A(k, j);
-          f = s / h;
-          for (k = i; k < m; k++) A(k, j) += f * A(k, i);
-        }
-        for (k = i; k < m; k++) A(k, i) *= scale;
-      }
-    }
-    w[i] = scale * g;
-    g = s = scale = 0.0;
-    if (i < m && i != n - 1) {
-      for (k = l; k < n; k++) scale += fabs(A(i, k));
-      if (scale) {
-        for (k = l; k < n; k++) { A(i, k) /= scale; s += A(i, k) * A(i, k); }
-        f = A(i, l);
-        g = -sign_of(sqrt(s), f);
-        h = f * g - s;
-        A(i, l) = f - g;
-        for (k = l; k < n; k++) rv1[k] = A(i, k) / h;
-        for (j = l; j < m; j++) {
-          for (s = 0.0, k = l; k < n; k++) s += A(j, k) * A(i, k);
-          for (k = l; k < n; k++) A(j, k) += s * rv1[k];
-        }
-        for (k = l; k < n; k++) A(i, k) *= scale;
-      }
-    }
-    const double t = fabs(w[i]) + fabs(rv1[i]);
-    anorm = anorm > t ? anorm : t;
-  }
-  for (i = n - 1; i >= 0; i--) {
-    if (i < n - 1) {
-      if (g) {
-        for (j = l; j < n; j++) V(j, i) = (A(i, j) / A(i, l)) / g;
-        for (j = l; j < n; j++) {
-          for (s = 0.0, k = l; k < n; k++) s += A(i, k) * V(k, j);
-          for (k = l; k < n; k++) V(k, j) += s * V(k, i);
-        }
-      }
-      for (j = l; j < n; j++) V(i, j) = V(j, i) = 0.0;
-    }
-    V(i, i) = 1.0;
-    g = rv1[i];
-    l = i;
-  }
-  for (i = (m < n ? m : n) - 1; i >= 0; i--) {
-    l = i + 1;
-    g = w[i];
-    for (j = l; j < n; j++) A(i, j) = 0.0;
-    if (g) {
-      g = 1.0 / g;
-      for (j = l; j < n; j++) {
-        for (s = 0.0, k = l; k < m; k++) s += A(k, i) * A(k, j);
-        f = (s / A(i, i)) * g;
-        for (k = i; k < m; k++) A(k, j) += f * A(k, i);
-      }
-      for (j = i; j < m; j++) A(j, i) *= g;
-    } else
-      for (j = i; j < m; j++) A(j, i) = 0.0;
-    ++A(i, i);
-  }
-  svd_qr_phase(n, w, rv1, anorm,
-    [&](int ca, int cb, double c, double s_) {
-      for (int r = 0; r < m; r++) { const double y = A(r, ca), z = A(r, cb); A(r, ca) = y * c + z * s_; A(r, cb) = z * c - y * s_; }
-    },
-    [&](int ca, int cb, double c, double s_) {
-      for (int r = 0; r < n; r++) { const double x = V(r, ca), z = V(r, cb); V(r, ca) = x * c + z * s_; V(r, cb) = z * c - x * s_; }
-    },
-    [&](int col) { for (int r = 0; r < n; r++) V(r, col) = -V(r, col); });
-  svd_sort_phase(n, w,
-    [&](int col) { for (int r = 0; r < m; r++) su[r] = A(r, col); for (int r = 0; r < n; r++) sv[r] = V(r, col); },
-    [&](int dst, int src) { for (int r = 0; r < m; r++) A(r, dst) = A(r, src); for (int r = 0; r < n; r++) V(r, dst) = V(r, src); },
-    [&](int col) { for (int r = 0; r < m; r++) A(r, col) = su[r]; for (int r = 0; r < n; r++) V(r, col) = sv[r]; });
-  for (k = 0; k < n; k++) {  // flip signs
-    int s2 = 0;
-    for (i = 0; i < m; i++) if (A(i, k) < 0.0) s2++;
-    for (j = 0; j < n; j++) if (V(j, k) < 0.0) s2++;
-    if (s2 > (m + n) / 2) {
-      for (i = 0; i < m; i++) A(i, k) = -A(i, k);
-      for (j = 0; j < n; j++) V(j, k) = -V(j, k);
-    }
-  }
-#undef A
-#undef V
-}
-
 // C = A (ma x na) * B (na x nb): Matrix::operator* (src/matrix.cpp:263-277), sums from 0, k ascending
 __device__ void matmul(const double *A, int ma, int na, const double *B, int nb, double *C) {
   for (int i = 0; i < ma; i++)
