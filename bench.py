@@ -168,16 +168,89 @@ def stream_assignment(rank: int, n_streams: int):
     return out
 
 
+class RankProtocol:
+    """The multi-rank control flow of the bench, backend-agnostic: process group over RCCL ("nccl", one rank per GPU) or,
+    for the CPU rehearsal, gloo.  Ranks never exchange data -- the path partitions by camera sequence -- only the
+    barrier, the gathered rank descriptions, the number of blocks and the MAX-reduced block time cross ranks."""
+
+    def __init__(self, backend, rank, local_rank, world, force=False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.local_rank, self.world, self.backend = rank, local_rank, world, backend
+        self.active = world > 1 or force
+        self.dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+        if self.active:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:  # (only a single-process rehearsal lacks it; torch.distributed.run sets it)
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=self.dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier(self):
+        if self.active:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
+
+    def gather(self, me):
+        """Every rank's description, on every rank (rank 0 checks them)."""
+        if not self.active:
+            return [me]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, me)
+        return out
+
+    def max_over_ranks(self, x, dtype=None):
+        t = self.torch.tensor([x], dtype=dtype or self.torch.float64, device=self.dev)
+        if self.active:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item()
+
+    def timed_blocks(self, step, fence, steps, blocks):
+        """Blocks of EXACTLY `steps` steps, each between two fences, each block's time the MAX over ranks; as many
+        blocks as make the timed region >= 0.5 s (at least 3, the same number on every rank) unless `blocks` says so."""
+        def block():
+            t0 = time.perf_counter()
+            for _ in range(steps):  # the timed region: no per-kernel events in it
+                step()
+            fence()
+            return float(self.max_over_ranks(time.perf_counter() - t0))
+        block_s = [block()]
+        n_blocks = blocks if blocks > 0 else max(3, min(50, int(np.ceil(0.5 / max(block_s[0], 1e-6)))))
+        n_blocks = int(self.max_over_ranks(n_blocks, self.torch.int64))  # every rank must run the same number of blocks
+        while len(block_s) < n_blocks:
+            block_s.append(block())
+        return block_s
+
+    def close(self):
+        if self.active:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+def check_ranks(ranks_seen, world):
+    devs = {(r["pci_bus_id"], r["pci_device_id"], r["uuid"]) for r in ranks_seen}
+    assert len(ranks_seen) == world and sorted(r["rank"] for r in ranks_seen) == list(range(world)), f"ranks missing: {ranks_seen}"
+    assert len(devs) == world or (len(devs) == 1 and world == 1), f"ranks share a GPU: {ranks_seen}"
+
+
 def dist_selftest(args):
-    """world_size>1 on CPU (gloo): every rank takes its own streams, ranks meet
-    at a barrier, time a fake step loop, and rank 0 reports the whole-job value
-    from the MAX over ranks -- the same control flow as the GPU bench."""
-    import torch
-    import torch.distributed as dist
+    """world_size>1 on CPU (gloo): main()'s own control flow -- RankProtocol: process group, gathered rank
+    descriptions, fence, timed blocks with the MAX-reduced clock and the agreed block count, final barrier -- around a
+    stubbed step (rank r sleeps r+1 ms per step, so the slowest rank must set the clock) and the real sharding."""
     rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
+    proto = RankProtocol("gloo", rank, local_rank, world)
     pkg = entry.load_package()
     S = args.streams
     mine = stream_assignment(rank, S)
@@ -185,27 +258,30 @@ def dist_selftest(args):
     digest = 0
     for gs, seed, phase in mine[:2]:
         digest ^= pkg.synth.fnv1a64(pkg.synth.frame(64, 32, phase % 20, 0, 2, 1, seed)[:4])
-    ids = torch.tensor([m[0] for m in mine], dtype=torch.int64)
-    gathered = [torch.zeros_like(ids) for _ in range(world)]
-    dist.all_gather(gathered, ids)
-    all_ids = torch.cat(gathered).tolist()
-    dig = torch.tensor([digest & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64)
-    digs = [torch.zeros_like(dig) for _ in range(world)]
-    dist.all_gather(digs, dig)
-    dist.barrier()
-    t0 = time.perf_counter()
-    time.sleep(0.05 * (rank + 1))  # ranks finish at different times: the slowest one must set the clock
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([0.05 * (rank + 1)], dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    me = {"rank": rank, "local_rank": local_rank, "device": local_rank, "name": "cpu-rehearsal", "pci_bus_id": local_rank, "pci_device_id": 0,
+          "uuid": f"fake-{local_rank}", "stream_ids": [m[0] for m in mine], "digest": digest & 0x7FFFFFFFFFFFFFFF}
+    ranks_seen = proto.gather(me)
     if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": world, "streams_per_gpu": S,
-                          "global_stream_ids": all_ids, "distinct_data": len({int(d.item()) for d in digs}) == world,
-                          "max_rank_time": float(tt.item()), "wall": dt,
-                          "value": world * S * args.steps / float(tt.item())}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+        check_ranks(ranks_seen, world)
+
+    def step():
+        time.sleep(0.001 * (rank + 1))
+
+    def fence():
+        proto.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    block_s = proto.timed_blocks(step, fence, args.steps, args.blocks)
+    dt = float(np.median(block_s))
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "streams_per_gpu": S, "steps": args.steps,
+                          "global_stream_ids": [i for r in sorted(ranks_seen, key=lambda r_: r_["rank"]) for i in r["stream_ids"]],
+                          "distinct_data": len({r["digest"] for r in ranks_seen}) == world,
+                          "ranks_seen": ranks_seen, "blocks": {"count": len(block_s), "seconds_each": block_s},
+                          "ms_per_step": 1e3 * dt / args.steps, "value": world * S * args.steps / dt}), flush=True)
+    proto.close()
 
 
 def main():
@@ -225,6 +301,11 @@ def main():
     ap.add_argument("--noise-frac", type=float, default=1.0, help="context runs: share of the pixels that receive --noise")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the as-shipped-loop measurement (e2e_matchfeatures)")
+    ap.add_argument("--no-e2e-host", action="store_true", help="skip the host-vote form of the as-shipped loop")
+    ap.add_argument("--e2e-steps-per-batch", type=int, default=int(os.environ.get("VH_E2E_STEPS_PER_BATCH", "4")))
+    ap.add_argument("--e2e-batches", type=int, default=int(os.environ.get("VH_E2E_BATCHES", "4")))
+    ap.add_argument("--e2e-lanes", type=int, default=int(os.environ.get("VH_E2E_LANES", "1")))
+    ap.add_argument("--e2e-steps", type=int, default=0, help="steps of the device e2e loop (0: 4 x the steps in flight, at least 48)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
@@ -239,40 +320,34 @@ def main():
     if args.dist_selftest:
         return dist_selftest(args)
 
+    # Rank 0 prints ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at
+    # initialisation): the process's fd 1 is pointed at stderr for the run, the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or bool(os.environ.get("VH_BENCH_FORCE_DIST"))  # the env switch rehearses the RCCL plumbing on one GPU
-    if world != args.gpus and not os.environ.get("VH_BENCH_FORCE_DIST"):
+    force_dist = bool(os.environ.get("VH_BENCH_FORCE_DIST"))  # the env switch rehearses the RCCL plumbing on one GPU
+    if world != args.gpus and not force_dist:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU "
                          "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
-    if use_dist:
-        # RCCL only carries the barrier and the MAX-reduced timing: streams never exchange data
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:  # (only the single-process rehearsal lacks it; torch.distributed.run sets it)
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # RCCL only carries the barrier and the MAX-reduced timing: streams never exchange data
+    proto = RankProtocol("nccl", rank, local_rank, world, force=force_dist)
+    use_dist = proto.active
     # which device every rank really sits on: (rank, local rank, device index, PCI bus id), gathered to rank 0
     props = torch.cuda.get_device_properties(local_rank)
     me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
           "pci_bus_id": getattr(props, "pci_bus_id", None), "pci_device_id": getattr(props, "pci_device_id", None),
           "uuid": str(getattr(props, "uuid", ""))}
-    ranks_seen = [me]
-    if use_dist:
-        ranks_seen = [None] * world
-        dist.all_gather_object(ranks_seen, me)
-        if rank == 0:
-            devs = {(r["pci_bus_id"], r["pci_device_id"], r["uuid"]) for r in ranks_seen}
-            assert len(ranks_seen) == world and (len(devs) == world or len(devs) == 1 and world == 1), \
-                f"ranks share a GPU: {ranks_seen}"
+    ranks_seen = proto.gather(me)
+    if rank == 0:
+        check_ranks(ranks_seen, world)
 
     pkg = entry.load_package()
     S, T = args.streams, args.frames
@@ -295,8 +370,7 @@ def main():
     def fence():
         grp.synchronize()  # the group's internal detect/match streams
         torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier(device_ids=[local_rank])
+        proto.barrier()
         torch.cuda.synchronize()
 
     k = 0
@@ -304,29 +378,14 @@ def main():
         step(k); k += 1
     fence()
 
-    def timed_block():
-        """EXACTLY --steps steps between two fences; MAX over ranks."""
+    def one_step():
         nonlocal k
-        t0 = time.perf_counter()
-        for _ in range(args.steps):  # the timed region: no per-kernel events in it
-            step(k); k += 1
-        fence()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        step(k); k += 1
 
     # One block of K steps is ~0.1 s at the default K: a single scheduler hiccup would be 5 % of it.  So the
-    # block is repeated (every one under the same protocol) until >= 0.5 s have been timed, and the MEDIAN block
-    # is the one reported; all block times are in the line.
-    block_s = [timed_block()]
-    n_blocks = args.blocks if args.blocks > 0 else max(3, min(50, int(np.ceil(0.5 / max(block_s[0], 1e-6)))))
-    if use_dist:  # every rank must run the same number of blocks
-        nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev)
-        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
-        n_blocks = int(nb.item())
-    while len(block_s) < n_blocks:
-        block_s.append(timed_block())
+    # block is repeated (every one under the same protocol: EXACTLY --steps steps between two fences, MAX over
+    # ranks) until >= 0.5 s have been timed, and the MEDIAN block is the one reported; all block times are in the line.
+    block_s = proto.timed_blocks(one_step, fence, args.steps, args.blocks)
     dt = float(np.median(block_s))
 
     # per-kernel device time: the same loop once more with HIP events recorded around every
@@ -361,36 +420,64 @@ def main():
             g2.matchFeatures(pkg.METHOD_QUAD)
         prof_excl = profiled(g2, min(args.steps, 12), 3)
         g2.close()
-    # ---- the as-shipped loop (a separate key, never the headline `value`): Matcher::matchFeatures is matching +
+    # ---- the as-shipped loop (separate keys, never the headline `value`): Matcher::matchFeatures is matching +
     # removeOutliers (src/matcher.cpp:104-108), VisualOdometryStereo::process goes on with bucketFeatures(2, 50, 50) and
-    # estimateMotion (src/viso_stereo.cpp:40-51).  The Delaunay vote is host work: step t's
-    # vote + bucketing run on the host threads while the GPU computes step t+1, then the batched egomotion kernel.
-    e2e = None
+    # estimateMotion (src/viso_stereo.cpp:40-51).  `e2e_matchfeatures`: all of it on the GPU (kernels_vote.hip: the
+    # Delaunay vote as one lane per match list, several steps in flight); `e2e_matchfeatures_host_vote`: round 3's form,
+    # vote + bucketing of step t on the host threads while the GPU computes step t+1.
+    e2e = e2e_host = None
     if not args.no_e2e and args.workload == "kitti" and world == 1:  # (like cpu_baseline: a context measurement of the N = 1 run)
         nthr = max(1, min(len(os.sched_getaffinity(0)), 16))
         ego = pkg.EgoParams.default(f=645.24, cu=635.96, cv=194.13, base=0.5707)
         r3 = np.random.default_rng(7).integers(0, 2 ** 31 - 1, (S, ego.ransac_iters, 3)).astype(np.int32)
         cap_ps = int(min(wl["cap"], max(1024, int(nm_max_hint(grp) * 1.25))))
-        n_e2e = max(4, min(args.steps, 12))
-        host_ms, ok_share = [], []
+        e2e_metric = "stereo frame-pairs/sec, as-shipped loop: detect + quad match + removeOutliers + bucketFeatures(2,50,50) + stereo estimateMotion"
+        # -- device form
+        B, NB, lanes = args.e2e_steps_per_batch, args.e2e_batches, args.e2e_lanes
+        depth = B * (NB - 1)
+        n_e2e = args.e2e_steps if args.e2e_steps > 0 else max(4 * B * NB, 48)
+        grp.postDeviceConfig(B, NB, lanes)
         fence()
+        ok_share, fin_ms, cnts = [], [], []
         t0 = time.perf_counter()
-        for j in range(n_e2e + 1):
+        for j in range(n_e2e + depth):
             if j < n_e2e:
                 step(k); k += 1
-                grp.postBegin(cap_ps)
-            if j > 0:
-                r = grp.postFinish(1 if j < n_e2e else 0, 2, 50.0, 50.0, host_threads=nthr, ego=ego, rand3=r3, want_lists=False)
-                host_ms.append(r["host_ms"]); ok_share.append(float(r["ok"].mean()))
+                grp.postBeginDevice(cap_ps, 2, 50.0, 50.0, ego=ego, rand3=r3)
+            if j >= depth:
+                q = j - depth
+                tq = time.perf_counter()
+                r = grp.postFinishDevice(min(j, n_e2e - 1) - q)
+                fin_ms.append(1e3 * (time.perf_counter() - tq))
+                ok_share.append(float(r["ok"].mean())); cnts.append(float(r["counts"].mean()))
         fence()
         dt_e2e = time.perf_counter() - t0
-        e2e = {"metric": "stereo frame-pairs/sec, as-shipped loop: detect + quad match + removeOutliers + bucketFeatures(2,50,50) + stereo estimateMotion",
-               "value": S * n_e2e / dt_e2e, "unit": "pairs/s", "steps": n_e2e, "ms_per_step": 1e3 * dt_e2e / n_e2e,
-               "host_threads": nthr, "host_ms_per_step_vote_and_bucket": float(np.median(host_ms)),
-               "bucketed_matches_per_stream": float(r["counts"].mean()), "pose_ok_share": float(np.mean(ok_share)),
-               "download_slot_records_per_stream": cap_ps,
-               "bound": "host: the Delaunay vote of removeOutliers is a sequential float triangulation per stream "
-                        "(csrc/outliers.cpp); the GPU part of a step takes ms_per_step of the headline"}
+        e2e = {"metric": e2e_metric, "value": S * n_e2e / dt_e2e, "unit": "pairs/s", "steps": n_e2e, "ms_per_step": 1e3 * dt_e2e / n_e2e,
+               "where": "device: vote (one lane per match list), bucketing and pose estimate are kernels; the host only begins and finishes steps",
+               "host_ms_per_step_vote_and_bucket": 0.0, "host_ms_per_step_waiting_in_finish": float(np.median(fin_ms)),
+               "steps_per_batch": B, "batches_in_flight": NB, "lists_per_wave": lanes, "steps_in_flight": depth,
+               "timed_region": "all steps, including the fill and the drain of the pipeline",
+               "bucketed_matches_per_stream": float(np.mean(cnts)), "pose_ok_share": float(np.mean(ok_share)),
+               "slot_records_per_stream": cap_ps}
+        # -- host-vote form (round 3)
+        if not args.no_e2e_host:
+            n_h = max(4, min(args.steps, 12))
+            host_ms, ok_share = [], []
+            fence()
+            t0 = time.perf_counter()
+            for j in range(n_h + 1):
+                if j < n_h:
+                    step(k); k += 1
+                    grp.postBegin(cap_ps)
+                if j > 0:
+                    r = grp.postFinish(1 if j < n_h else 0, 2, 50.0, 50.0, host_threads=nthr, ego=ego, rand3=r3, want_lists=False)
+                    host_ms.append(r["host_ms"]); ok_share.append(float(r["ok"].mean()))
+            fence()
+            dt_h = time.perf_counter() - t0
+            e2e_host = {"metric": e2e_metric, "value": S * n_h / dt_h, "unit": "pairs/s", "steps": n_h, "ms_per_step": 1e3 * dt_h / n_h,
+                        "host_threads": nthr, "host_ms_per_step_vote_and_bucket": float(np.median(host_ms)),
+                        "bucketed_matches_per_stream": float(r["counts"].mean()), "pose_ok_share": float(np.mean(ok_share)),
+                        "bound": "host: the Delaunay vote of removeOutliers is a sequential float triangulation per stream (csrc/outliers.cpp)"}
     search_spec, search_redo = grp.searchStats()
     nf, nm = grp.getCounts()
     wl_radius = pkg.Params.default(**wl["params"]).match_radius
@@ -477,6 +564,7 @@ def main():
             "kernels_launches_per_step": {n_: round(v["launches"] / args.steps, 2) for n_, v in prof.items()},
             "kernels_us_per_launch_exclusive": {n_: round(v["us_per_launch"], 2) for n_, v in prof_excl.items()},
             "e2e_matchfeatures": e2e,
+            "e2e_matchfeatures_host_vote": e2e_host,
             "parity_scope": "primitives (computeFeatures, createIndexVector, findMatch, flow matching) pinned to the reference; "
                             "stereo/quad composition per SURVEY A.7 (absent from the reference: unpinned)",
         }
@@ -505,11 +593,9 @@ def main():
             f = [o.compute_features(p, frames_np[t_, c, 0], dims)[1] for t_ in (prev_t, last) for c in (0, 1)]
             want = o.matching(p, dims, 2, *f)
             out["parity_checked"] = bool(got0.tobytes() == want.tobytes())
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     grp.close()
-    if use_dist:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    proto.close()
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@ METHOD_FLOW, METHOD_STEREO, METHOD_QUAD = 0, 1, 2
 ABI_SYMBOLS = (
     "vh_abi_version", "vh_device_count", "vh_error_string", "vh_last_error", "vh_default_params",
     "vh_create", "vh_create_ex", "vh_destroy", "vh_set_intrinsics", "vh_push_back", "vh_push_back_device",
-    "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
+    "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_remove_outliers_device", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
     "vh_set_stream", "vh_clear_stream", "vh_stream_wait_images", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
     "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
@@ -46,6 +46,7 @@ ABI_SYMBOLS = (
     "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion", "vh_group_search_stats",
     "vh_default_mono_params", "vh_estimate_motion_mono", "vh_group_estimate_motion_mono",
     "vh_group_post_begin", "vh_group_post_finish", "vh_group_post_finish_mono",
+    "vh_group_post_device_config", "vh_group_post_begin_device", "vh_group_post_finish_device",
 )
 
 
@@ -148,6 +149,7 @@ def _lib():
             "vh_get_matches": [vp, vp, i32, vp], "vh_get_features": [vp, i32, vp, i32, vp],
             "vh_synchronize": [vp], "vh_set_stream": [vp, vp], "vh_clear_stream": [vp], "vh_stream_wait_images": [vp, vp],
             "vh_remove_outliers": [vp], "vh_remove_outliers_pm": [vp, i32, vp], "vh_group_remove_outliers": [vp, i32],
+            "vh_remove_outliers_device": [i32, i32, vp, i64, vp, i32, i32, f32, f32, vp, i32, vp, vp, vp],
             "vh_host_alloc": [i32, C.c_size_t, vp], "vh_host_free": [vp],
             "vh_compute_features": [vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp],
             "vh_filters": [i32, vp, i32, i32, vp, vp, vp, vp],
@@ -173,6 +175,9 @@ def _lib():
             "vh_group_post_begin": [vp, i32],
             "vh_group_post_finish": [vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp],
             "vh_group_post_finish_mono": [vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp],
+            "vh_group_post_device_config": [vp, i32, i32, i32],
+            "vh_group_post_begin_device": [vp, i32, i32, f32, f32, vp, vp, vp, vp, i32],
+            "vh_group_post_finish_device": [vp, i32, vp, vp, vp, vp, i32, vp],
             "vh_group_search_stats": [vp, vp, vp],
         }
         for name, args in sig.items():
@@ -478,6 +483,37 @@ class StreamGroup:
         lists = [out[s, :counts[s]].copy() for s in range(S)] if want_lists else None
         return {"tr": tr, "ok": ok.astype(bool), "n_inliers": ninl, "lists": lists, "counts": counts, "host_ms": ms.value}
 
+    def postDeviceConfig(self, steps_per_batch: int = 4, batches: int = 4, lanes_per_wave: int = 1):
+        """Shape of the device post stage's pipeline (vh_group_post_device_config)."""
+        _check(_lib().vh_group_post_device_config(self._h, int(steps_per_batch), int(batches), int(lanes_per_wave)), "vh_group_post_device_config")
+
+    def postBeginDevice(self, cap_per_stream: int, max_features: int, bucket_width: float, bucket_height: float,
+                        ego: "EgoParams" = None, rand3=None, mono: "MonoParams" = None, rand8=None, want_lists: bool = False):
+        """This step's match lists enter the device post stage: removeOutliers -> bucketFeatures -> estimateMotion, all on
+        the GPU (vh_group_post_begin_device)."""
+        r3 = r8 = None
+        if ego is not None:
+            r3 = np.ascontiguousarray(rand3, np.int32)
+            assert r3.shape == (self.S, ego.ransac_iters, 3)
+        if mono is not None:
+            r8 = np.ascontiguousarray(rand8, np.int32)
+            assert r8.shape == (self.S, mono.ransac_iters, 8)
+        _check(_lib().vh_group_post_begin_device(self._h, int(cap_per_stream), int(max_features), C.c_float(bucket_width), C.c_float(bucket_height),
+                                                 C.byref(ego) if ego is not None else None, _ptr(r3),
+                                                 C.byref(mono) if mono is not None else None, _ptr(r8), 1 if want_lists else 0),
+               "vh_group_post_begin_device")
+
+    def postFinishDevice(self, age: int, want_lists: bool = False, list_cap: int = 4096, estimator: bool = True):
+        """Results of the step begun `age` begins ago (vh_group_post_finish_device) -> dict(tr, ok, n_inliers, lists, counts)."""
+        S = self.S
+        tr = np.zeros((S, 6), np.float64); ok = np.zeros(S, np.int32); ninl = np.zeros(S, np.int32); counts = np.zeros(S, np.int32)
+        out = np.zeros((S, int(list_cap)), P_MATCH_DTYPE) if want_lists else None
+        _check(_lib().vh_group_post_finish_device(self._h, int(age), _ptr(tr) if estimator else None, _ptr(ok) if estimator else None,
+                                                  _ptr(ninl) if estimator else None, _ptr(out), int(list_cap) if want_lists else 0, _ptr(counts)),
+               "vh_group_post_finish_device")
+        lists = [out[s, :counts[s]].copy() for s in range(S)] if want_lists else None
+        return {"tr": tr, "ok": ok.astype(bool), "n_inliers": ninl, "lists": lists, "counts": counts}
+
     def estimateMotionMono(self, mono: "MonoParams", rand8):
         """VisualOdometryMono::estimateMotion (reference src/viso_mono.cpp:41-160) on every stream's device-resident
         flow (or quad) matches; rand8 [S, ransac_iters, 8] int32 rand() values -> (tr [S,6], ok [S], n_inliers [S])."""
@@ -614,6 +650,26 @@ def remove_outliers(pm) -> np.ndarray:
     n = C.c_int32(0)
     _check(_lib().vh_remove_outliers_pm(_ptr(pm), len(pm), C.byref(n)), "vh_remove_outliers_pm")
     return pm[:n.value].copy()
+
+
+def remove_outliers_device(lists, lanes_per_wave: int = 1, max_features: int = 0, bucket_width: float = 50.0, bucket_height: float = 50.0,
+                           device: int = 0, out_cap: int = 0):
+    """removeOutliers (and bucketFeatures when max_features >= 1) of several match lists at once on the GPU
+    (vh_remove_outliers_device) -> (lists, triangles per list, sweep kernel ms)."""
+    lists = [np.ascontiguousarray(m, dtype=P_MATCH_DTYPE) for m in lists]
+    n = len(lists)
+    stride = max([len(m) for m in lists] + [1])
+    pm = np.zeros((n, stride), P_MATCH_DTYPE)
+    for l, m in enumerate(lists):
+        pm[l, :len(m)] = m
+    counts = np.array([len(m) for m in lists], np.int32)
+    out_cap = int(out_cap) if out_cap else stride
+    out = np.zeros((n, out_cap), P_MATCH_DTYPE)
+    oc = np.zeros(n, np.int32); ntri = np.zeros(n, np.int32); ms = C.c_float(0.0)
+    _check(_lib().vh_remove_outliers_device(device, n, _ptr(pm), stride, _ptr(counts), int(lanes_per_wave), int(max_features),
+                                            C.c_float(bucket_width), C.c_float(bucket_height), _ptr(out), out_cap, _ptr(oc), _ptr(ntri),
+                                            C.byref(ms)), "vh_remove_outliers_device")
+    return [out[l, :oc[l]].copy() for l in range(n)], ntri, ms.value
 
 
 def match(param: Params, dims, method: int, m1p=None, m2p=None, m1c=None, m2c=None, device: int = 0, cap=None):

@@ -7,6 +7,7 @@
 // moving the current/previous roles between the slots of a ring; nothing is copied on pushBack.
 #include "vh_dev.h"
 #include "../../include/viso_hip.h"
+#include "vh_vote.h"
 
 #include <algorithm>
 #include <atomic>
@@ -161,6 +162,7 @@ struct Group {
     if (ev_down) (void)hipEventDestroy(ev_down);
     for (auto &sl : post_slot) if (sl.ev) (void)hipEventDestroy(sl.ev);
     if (down_stream) (void)hipStreamDestroy(down_stream);
+    for (int k = 0; k < kVoteStreams; k++) if (vote_stream[k]) (void)hipStreamDestroy(vote_stream[k]);
     for (int k = 0; k < 2; k++) { if (ev_tables[k]) (void)hipEventDestroy(ev_tables[k]); if (ev_post[k]) (void)hipEventDestroy(ev_post[k]); }
     if (post_stream && own_post) (void)hipStreamDestroy(post_stream);
     if (match_stream && !serial) (void)hipStreamDestroy(match_stream);
@@ -172,6 +174,7 @@ struct Group {
     VH_HIP(hipStreamSynchronize(match_stream));
     VH_HIP(hipStreamSynchronize(post_stream));
     VH_HIP(hipStreamSynchronize(down_stream));
+    for (int k = 0; k < kVoteStreams; k++) if (vote_stream[k]) VH_HIP(hipStreamSynchronize(vote_stream[k]));
     return check_violation();
   }
   // -DVH_CHECK builds: the kernels verify the index invariants they otherwise trust (vh_dev.h,
@@ -194,6 +197,7 @@ struct Group {
   }
 
   void release() {
+    vote_release();
     for (void *q : allocs) (void)hipFree(q);
     allocs.clear();
     device_bytes = 0;
@@ -887,13 +891,14 @@ struct Group {
     if (post_seq - 1 - age < 0) return VH_ERR_STATE;
     PostSlot &sl = post_slot[(post_seq - 1 - age) & 1];
     if (!sl.pending) return VH_ERR_STATE;
+    if (e && sl.method != VH_METHOD_QUAD) return VH_ERR_STATE;       // the stereo estimator needs both cameras of both frames
+    if (mono && sl.method == VH_METHOD_STEREO) return VH_ERR_STATE;  // the monocular one the left camera of both frames
+    int64_t need = 0;
+    { const int32_t rb = bucket_need(max_features, bw, bh, &need); if (rb) return rb; }  // (a bucket below one pixel is refused: the grid would not fit any index type)
     VH_HIP(hipEventSynchronize(sl.ev));
     sl.pending = false;
     for (int32_t s = 0; s < S; s++)
       if (sl.h_cnt[s] > sl.width || sl.h_cnt[S + s]) return VH_ERR_CAPACITY;  // a list longer than what was downloaded / a truncated feature set
-    // bucket grid bound: floor(u_max / bw) + 1 columns, floor(v_max / bh) + 1 rows (matcher.cpp:150-151)
-    const int64_t cols = (int64_t)floorf((float)(dims[0] - 1) / bw) + 1, rows = (int64_t)floorf((float)(dims[1] - 1) / bh) + 1;
-    const int64_t need = std::min<int64_t>(cols * rows * max_features, mcap);
     if (bcap < need) {
       if (h_bucket) { VH_HIP(hipHostFree(h_bucket)); h_bucket = nullptr; }
       VH_HIP(hipHostMalloc((void **)&h_bucket, sizeof(vh_p_match) * (size_t)S * need, hipHostMallocDefault));
@@ -936,8 +941,6 @@ struct Group {
       }
     }
     if (!e && !mono) return VH_OK;
-    if (e && sl.method != VH_METHOD_QUAD) return VH_ERR_STATE;  // the stereo estimator needs both cameras of both frames
-    if (mono && sl.method == VH_METHOD_STEREO) return VH_ERR_STATE;  // the monocular one the left camera of both frames
     const size_t nr = e ? (size_t)S * e->ransac_iters * 3 : (size_t)S * mono->ransac_iters * 8;
     if (post_rand_n < nr) { int32_t rc = dmalloc(&d_post_rand, nr, false); if (rc) return rc; post_rand_n = nr; }
     if (mono && post_mono_iters < mono->ransac_iters) {
@@ -959,6 +962,237 @@ struct Group {
     static const bool timing = [] { const char *ev_ = getenv("VH_POST_TIMING"); return ev_ && ev_[0] == '1'; }();
     if (timing) fprintf(stderr, "post_finish: host %.2f ms, upload + ego + results %.2f ms\n",
                         host_ms ? *host_ms : -1.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - (host_ms ? *host_ms : 0.0));
+    return VH_OK;
+  }
+
+  // ---- the steps after matching ON THE DEVICE ---------------------------------
+  // removeOutliers -> bucketFeatures -> estimateMotion without the host: kernels_vote.hip.  The triangulation
+  // under the vote is a sequential chain per list that takes tens of milliseconds as a GPU lane, so the
+  // throughput comes from lists in flight: post_begin_device() moves the step's S lists into the current
+  // BATCH (the matcher's buffer is free again at once); a batch of `vote_steps` steps is launched as one
+  // kernel sequence over vote_steps * S lists on one of a few low-priority streams (their own hardware
+  // queues: the long sweep kernel never stands in front of the matcher's kernels), and up to
+  // `vote_batches` batches are in flight.  post_finish_device(age) hands out the results of the step begun
+  // `age` begins ago, waiting for its batch if it has to -- a caller that stays vote_steps * (vote_batches - 1)
+  // steps ahead never waits.
+  struct VoteBatch {
+    VhVoteBuffers vb;
+    int32_t steps = 0;      // steps moved in so far
+    bool launched = false;  // the kernel sequence has been queued
+    bool busy = false;      // holds steps whose results have not all been handed out
+    int32_t handed = 0;
+    hipEvent_t ev_prep = nullptr, ev_done = nullptr;
+    int32_t method = -1, max_features = 0; float bw = 0, bh = 0;
+    bool has_ego = false, has_mono = false;
+    vh_ego_params ego{}; vh_mono_params mono{};
+    int32_t *d_rand = nullptr; size_t rand_per_step = 0;
+    double *d_xyz = nullptr, *d_tr = nullptr; int32_t *d_ok = nullptr; uint8_t *d_mono = nullptr;
+    uint8_t *block = nullptr;  // d_rand | d_xyz | d_tr | d_ok | d_mono
+    size_t block_bytes = 0;
+    // page-locked results
+    double *h_tr = nullptr; int32_t *h_ok = nullptr; int32_t *h_cnt = nullptr; VhVoteMeta *h_meta = nullptr; vh_p_match *h_out = nullptr;
+    int32_t h_lists = 0, h_out_cap = 0;
+    bool want_lists = false;
+    void free_all() {
+      vb.release();
+      if (block) (void)hipFree(block);
+      block = nullptr; block_bytes = 0; d_rand = nullptr; d_xyz = nullptr; d_tr = nullptr; d_ok = nullptr; d_mono = nullptr;
+      for (void *q : {(void *)h_tr, (void *)h_ok, (void *)h_cnt, (void *)h_meta, (void *)h_out}) if (q) (void)hipHostFree(q);
+      h_tr = nullptr; h_ok = nullptr; h_cnt = nullptr; h_meta = nullptr; h_out = nullptr; h_lists = 0; h_out_cap = 0;
+      steps = 0; launched = false; busy = false; handed = 0;
+    }
+  };
+  static constexpr int32_t kVoteStreams = 4;
+  std::vector<VoteBatch> vbatch;
+  hipStream_t vote_stream[kVoteStreams] = {};
+  int32_t vote_steps = 4, vote_batches = 4, vote_lanes = 1;
+  int64_t post_dev_seq = 0;   // steps begun
+  int32_t vote_cur = 0;       // batch receiving steps
+  struct VoteStep { int32_t batch = -1, pos = 0; bool open = false; };
+  std::vector<VoteStep> vstep;  // ring over the steps begun, indexed by sequence number
+
+  void vote_release() {
+    for (auto &b : vbatch) {
+      if (b.ev_done && b.launched) (void)hipEventSynchronize(b.ev_done);
+      b.free_all();
+      if (b.ev_prep) (void)hipEventDestroy(b.ev_prep);
+      if (b.ev_done) (void)hipEventDestroy(b.ev_done);
+    }
+    vbatch.clear(); vstep.clear(); post_dev_seq = 0; vote_cur = 0;
+  }
+
+  int32_t post_device_config(int32_t steps_per_batch, int32_t batches, int32_t lanes) {
+    if (steps_per_batch < 1 || steps_per_batch > 64 || batches < 1 || batches > 64 || lanes < 1 || lanes > 64) return VH_ERR_INVALID_ARG;
+    for (auto &b : vbatch) if (b.busy || b.steps) return VH_ERR_STATE;  // steps in flight
+    vote_release();
+    vote_steps = steps_per_batch; vote_batches = batches; vote_lanes = lanes;
+    return VH_OK;
+  }
+
+  // bucket grid of Matcher::bucketFeatures on this group's images: floor(u_max / bw) + 1 columns, floor(v_max / bh) + 1 rows (matcher.cpp:150-151)
+  int32_t bucket_need(int32_t max_features, float bw, float bh, int64_t *need) const {
+    if (max_features < 1 || !(bw >= 1) || !(bh >= 1)) return VH_ERR_INVALID_ARG;
+    const int64_t cols = (int64_t)floorf((float)(dims[0] - 1) / bw) + 1, rows = (int64_t)floorf((float)(dims[1] - 1) / bh) + 1;
+    if (cols * rows > (1 << 20)) return VH_ERR_UNSUPPORTED;
+    *need = std::min<int64_t>(cols * rows * max_features, mcap);
+    return VH_OK;
+  }
+
+  int32_t vote_launch(VoteBatch &b, int32_t index) {
+    if (b.launched || b.steps == 0) return VH_OK;
+    hipStream_t vs = vote_stream[index % kVoteStreams];
+    VhVote v = b.vb.v;
+    v.P = b.steps * S;
+    VH_HIP(hipStreamWaitEvent(vs, b.ev_prep, 0));
+    vh_launch_vote(v, vote_lanes, b.max_features, b.bw, b.bh, b.vb.lfsr, b.vb.lfsr_n, b.vb.out, b.vb.out_cap, b.vb.out_count, nullptr, vs);
+    VH_HIP(hipGetLastError());
+    if (b.has_ego) vh_launch_ego(b.ego, v.P, b.vb.out, b.vb.out_cap, nullptr, b.vb.out_count, b.vb.out_cap, b.d_rand, b.d_xyz, b.vb.out_cap, b.d_tr, b.d_ok, b.d_ok + v.P, nullptr, 0, vs);
+    else if (b.has_mono) vh_launch_mono(b.mono, v.P, b.vb.out, b.vb.out_cap, nullptr, b.vb.out_count, b.vb.out_cap, b.d_rand, b.d_mono, b.vb.out_cap, b.d_tr, b.d_ok, b.d_ok + v.P, nullptr, 0, vs);
+    VH_HIP(hipGetLastError());
+    if (b.has_ego || b.has_mono) {
+      VH_HIP(hipMemcpyAsync(b.h_tr, b.d_tr, sizeof(double) * 6 * (size_t)v.P, hipMemcpyDeviceToHost, vs));
+      VH_HIP(hipMemcpyAsync(b.h_ok, b.d_ok, sizeof(int32_t) * 2 * (size_t)v.P, hipMemcpyDeviceToHost, vs));
+    }
+    VH_HIP(hipMemcpyAsync(b.h_cnt, b.vb.out_count, sizeof(int32_t) * (size_t)v.P, hipMemcpyDeviceToHost, vs));
+    VH_HIP(hipMemcpyAsync(b.h_meta, b.vb.v.meta, sizeof(VhVoteMeta) * (size_t)v.P, hipMemcpyDeviceToHost, vs));
+    if (b.want_lists) VH_HIP(hipMemcpyAsync(b.h_out, b.vb.out, sizeof(vh_p_match) * (size_t)v.P * b.vb.out_cap, hipMemcpyDeviceToHost, vs));
+    VH_HIP(hipEventRecord(b.ev_done, vs));
+    b.launched = true;
+    return VH_OK;
+  }
+
+  int32_t post_begin_device(int32_t cap_ps, int32_t max_features, float bw, float bh, const vh_ego_params *e, const int32_t *rand3,
+                            const vh_mono_params *mono, const int32_t *rand8, int32_t want_lists) {
+    if (cap_ps < 1 || (e && mono)) return VH_ERR_INVALID_ARG;
+    if (e && (!rand3 || e->ransac_iters < 1)) return VH_ERR_INVALID_ARG;
+    if (mono && (!rand8 || mono->ransac_iters < 1 || (int64_t)S * vote_steps * mono->ransac_iters > (int64_t)1 << 31)) return VH_ERR_INVALID_ARG;
+    if (!allocated || last_method < 0) return VH_ERR_STATE;
+    if (e && last_method != VH_METHOD_QUAD) return VH_ERR_STATE;        // the stereo estimator needs both cameras of both frames
+    if (mono && last_method == VH_METHOD_STEREO) return VH_ERR_STATE;   // the monocular one the left camera of both frames
+    int64_t need = 0;
+    int32_t rc = bucket_need(max_features, bw, bh, &need);
+    if (rc) return rc;
+    cap_ps = std::min(cap_ps, mcap);
+    if (vbatch.empty()) {
+      vbatch.resize((size_t)vote_batches);
+      vstep.assign((size_t)vote_steps * vote_batches, VoteStep{});
+      int prio_lo = 0, prio_hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      for (int k = 0; k < kVoteStreams; k++)
+        if (!vote_stream[k]) VH_HIP(hipStreamCreateWithPriority(&vote_stream[k], hipStreamNonBlocking, prio_lo));
+      for (auto &b : vbatch) {
+        VH_HIP(hipEventCreateWithFlags(&b.ev_prep, hipEventDisableTiming));
+        VH_HIP(hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming));
+      }
+    }
+    VoteBatch *b = &vbatch[(size_t)vote_cur];
+    const size_t rand_per_step = e ? (size_t)S * e->ransac_iters * 3 : (mono ? (size_t)S * mono->ransac_iters * 8 : 0);
+    const auto same = [&](const VoteBatch &q) {
+      return q.method == last_method && q.max_features == max_features && q.bw == bw && q.bh == bh && q.has_ego == (e != nullptr) &&
+             q.has_mono == (mono != nullptr) && (!e || memcmp(&q.ego, e, sizeof(*e)) == 0) && (!mono || memcmp(&q.mono, mono, sizeof(*mono)) == 0) &&
+             q.vb.v.cap >= cap_ps && q.want_lists == (want_lists != 0);
+    };
+    if (b->steps > 0 && (b->launched || b->steps >= vote_steps || !same(*b))) {  // the batch is closed (full, flushed, or configured differently): next one
+      if ((rc = vote_launch(*b, vote_cur))) return rc;
+      vote_cur = (vote_cur + 1) % vote_batches;
+      b = &vbatch[(size_t)vote_cur];
+    }
+    if (b->steps == 0 || b->launched) {  // start the batch
+      if (b->launched) {  // the ring has come round: its results must have been handed out, its kernels are done
+        if (b->busy && b->handed < b->steps) return VH_ERR_STATE;  // results of `vote_steps * vote_batches` steps ago were never fetched
+        VH_HIP(hipEventSynchronize(b->ev_done));
+      }
+      b->steps = 0; b->launched = false; b->busy = false; b->handed = 0;
+      const int32_t P = vote_steps * S;
+      if (b->vb.v.cap < cap_ps || b->vb.out_cap < need || b->vb.v.P < P) {
+        b->vb.release();
+        VH_HIP(b->vb.alloc(P, cap_ps, (int32_t)need));
+        VH_HIP(b->vb.upload_lfsr());
+      }
+      const int32_t ocap = b->vb.out_cap;
+      const auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+      const size_t b_rand = up(sizeof(int32_t) * rand_per_step * vote_steps), b_xyz = up(e ? sizeof(double) * 4 * (size_t)P * ocap : 0), b_tr = up(sizeof(double) * 6 * (size_t)P),
+                   b_ok = up(sizeof(int32_t) * 2 * (size_t)P), b_mono = mono ? (size_t)vh_mono_scratch_bytes(P, ocap, mono->ransac_iters) : 0;
+      if (b->block_bytes < b_rand + b_xyz + b_tr + b_ok + b_mono || b->rand_per_step != rand_per_step) {
+        if (b->block) (void)hipFree(b->block);
+        b->block = nullptr; b->block_bytes = 0;
+        VH_HIP(hipMalloc((void **)&b->block, b_rand + b_xyz + b_tr + b_ok + b_mono + 256));
+        b->block_bytes = b_rand + b_xyz + b_tr + b_ok + b_mono;
+      }
+      b->d_rand = (int32_t *)b->block; b->d_xyz = (double *)(b->block + b_rand); b->d_tr = (double *)(b->block + b_rand + b_xyz);
+      b->d_ok = (int32_t *)(b->block + b_rand + b_xyz + b_tr); b->d_mono = b->block + b_rand + b_xyz + b_tr + b_ok;
+      b->rand_per_step = rand_per_step;
+      if (b->h_lists < P) {
+        for (void *q : {(void *)b->h_tr, (void *)b->h_ok, (void *)b->h_cnt, (void *)b->h_meta}) if (q) (void)hipHostFree(q);
+        b->h_tr = nullptr; b->h_ok = nullptr; b->h_cnt = nullptr; b->h_meta = nullptr;
+        VH_HIP(hipHostMalloc((void **)&b->h_tr, sizeof(double) * 6 * (size_t)P, hipHostMallocDefault));
+        VH_HIP(hipHostMalloc((void **)&b->h_ok, sizeof(int32_t) * 2 * (size_t)P, hipHostMallocDefault));
+        VH_HIP(hipHostMalloc((void **)&b->h_cnt, sizeof(int32_t) * (size_t)P, hipHostMallocDefault));
+        VH_HIP(hipHostMalloc((void **)&b->h_meta, sizeof(VhVoteMeta) * (size_t)P, hipHostMallocDefault));
+        b->h_lists = P;
+      }
+      if (want_lists && (!b->h_out || b->h_out_cap < ocap)) {
+        if (b->h_out) (void)hipHostFree(b->h_out);
+        b->h_out = nullptr;
+        VH_HIP(hipHostMalloc((void **)&b->h_out, sizeof(vh_p_match) * (size_t)P * ocap, hipHostMallocDefault));
+        b->h_out_cap = ocap;
+      }
+      b->method = last_method; b->max_features = max_features; b->bw = bw; b->bh = bh; b->has_ego = e != nullptr; b->has_mono = mono != nullptr;
+      if (e) b->ego = *e;
+      if (mono) b->mono = *mono;
+      b->want_lists = want_lists != 0;
+    }
+    // the step's lists leave the matcher's buffer behind the emission that wrote them; the next emission waits for that (ev_down)
+    VH_HIP(hipStreamWaitEvent(down_stream, ev_post[last_buf], 0));
+    vh_launch_vote_prep(b->vb.v, b->steps * S, S, (const vh_p_match *)d_matches, mcap, d_match_count, mcap, d_overflow, last_method != VH_METHOD_STEREO ? 1 : 0, down_stream);
+    VH_HIP(hipGetLastError());
+    if (rand_per_step)
+      VH_HIP(hipMemcpyAsync(b->d_rand + rand_per_step * (size_t)b->steps, e ? rand3 : rand8, sizeof(int32_t) * rand_per_step, hipMemcpyHostToDevice, down_stream));
+    VH_HIP(hipEventRecord(b->ev_prep, down_stream));
+    VH_HIP(hipEventRecord(ev_down, down_stream)); ev_down_valid = true;
+    VoteStep &st = vstep[(size_t)(post_dev_seq % (int64_t)vstep.size())];
+    st.batch = vote_cur; st.pos = b->steps; st.open = true;
+    b->steps++; b->busy = true;
+    post_dev_seq++;
+    if (b->steps >= vote_steps) return vote_launch(*b, vote_cur);
+    return VH_OK;
+  }
+
+  int32_t post_finish_device(int32_t age, double *tr, int32_t *ok, int32_t *ninl, vh_p_match *out, int32_t out_cap, int32_t *out_counts) {
+    if (age < 0 || (out && out_cap < 1)) return VH_ERR_INVALID_ARG;
+    if (vstep.empty() || post_dev_seq - 1 - age < 0 || age >= (int64_t)vstep.size()) return VH_ERR_STATE;
+    VoteStep &st = vstep[(size_t)((post_dev_seq - 1 - age) % (int64_t)vstep.size())];
+    if (!st.open) return VH_ERR_STATE;
+    VoteBatch &b = vbatch[(size_t)st.batch];
+    int32_t rc = vote_launch(b, st.batch);  // (a batch that is not full yet is closed and launched now)
+    if (rc) return rc;
+    VH_HIP(hipEventSynchronize(b.ev_done));
+    st.open = false;
+    b.handed++;
+    if (b.handed >= b.steps) b.busy = false;
+    const size_t p0 = (size_t)st.pos * S, P = (size_t)b.steps * S;
+    int32_t ret = VH_OK;
+    for (int32_t s = 0; s < S; s++) {
+      const VhVoteMeta &m = b.h_meta[p0 + s];
+      if (m.status == VH_VOTE_TRUNCATED) ret = VH_ERR_CAPACITY;
+      else if (m.status != VH_VOTE_OK && m.status != VH_VOTE_SKIP && ret == VH_OK) ret = VH_ERR_UNSUPPORTED;
+    }
+    if (ret) return ret;
+    if ((b.has_ego || b.has_mono) && (!tr || !ok || !ninl)) return VH_ERR_INVALID_ARG;
+    if (b.has_ego || b.has_mono) {
+      memcpy(tr, b.h_tr + 6 * p0, sizeof(double) * 6 * (size_t)S);
+      memcpy(ok, b.h_ok + p0, sizeof(int32_t) * (size_t)S);
+      memcpy(ninl, b.h_ok + P + p0, sizeof(int32_t) * (size_t)S);
+    }
+    if (out_counts) memcpy(out_counts, b.h_cnt + p0, sizeof(int32_t) * (size_t)S);
+    if (out) {
+      if (!b.want_lists) return VH_ERR_STATE;
+      for (int32_t s = 0; s < S; s++) {
+        const int32_t k = b.h_cnt[p0 + s];
+        if (k > out_cap) return VH_ERR_CAPACITY;
+        memcpy(out + (size_t)s * out_cap, b.h_out + (p0 + s) * (size_t)b.vb.out_cap, sizeof(vh_p_match) * (size_t)k);
+      }
+    }
     return VH_OK;
   }
 
@@ -984,17 +1218,7 @@ struct Group {
   }
 };
 
-// Matcher::rand_number (matcher.cpp:113-124): LFSR, taps {32,22,2,1}, evaluated
-// by the reference in double arithmetic; its int(floor(number/2^0)) term is an
-// out-of-range double->int conversion for number >= 2^31, which on x86-64
-// (cvttsd2si) produces INT_MIN, i.e. a 0 low bit.
-uint32_t lfsr_next(uint32_t x) {
-  uint32_t b = (x < 0x80000000u) ? (x & 1u) : 0u;
-  b ^= (x >> 10) & 1u;
-  b ^= (x >> 30) & 1u;
-  b ^= (x >> 31) & 1u;
-  return (x >> 1) + (b << 31);
-}
+uint32_t lfsr_next(uint32_t x) { return vh_lfsr_next(x); }  // (vh_vote.h: shared with the device form of the shuffle)
 
 // Matcher::bucketFeatures (matcher.cpp:140-187) without the fixed
 // buckets[126][256] capacity.
@@ -1465,6 +1689,21 @@ int32_t vh_group_post_finish_mono(vh_group *g, int32_t age, int32_t max_features
   return gq->post_finish(age, max_features, bucket_width, bucket_height, host_threads, nullptr, nullptr, e, rand8, tr, ok, n_inliers, bucketed, cap_per_stream, counts, host_ms);
 }
 
+int32_t vh_group_post_device_config(vh_group *g, int32_t steps_per_batch, int32_t batches, int32_t lanes_per_wave) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->post_device_config(steps_per_batch, batches, lanes_per_wave);
+}
+int32_t vh_group_post_begin_device(vh_group *g, int32_t cap_per_stream, int32_t max_features, float bucket_width, float bucket_height,
+                                   const vh_ego_params *e, const int32_t *rand3, const vh_mono_params *mono, const int32_t *rand8, int32_t want_lists) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->post_begin_device(cap_per_stream, max_features, bucket_width, bucket_height, e, rand3, mono, rand8, want_lists);
+}
+int32_t vh_group_post_finish_device(vh_group *g, int32_t age, double *tr, int32_t *ok, int32_t *n_inliers, vh_p_match *bucketed, int32_t cap_per_stream,
+                                    int32_t *counts) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->post_finish_device(age, tr, ok, n_inliers, bucketed, cap_per_stream, counts);
+}
+
 // ---- monocular egomotion -----------------------------------------
 void vh_default_mono_params(vh_mono_params *e) {
   if (!e) return;
@@ -1668,6 +1907,56 @@ int32_t vh_match(const vh_params *p, int32_t device, const int32_t dims[3], int3
   if ((rc = gq->load_features(VH_SET_2C, m2c, n2c))) return rc;
   if ((rc = gq->match(method))) return rc;
   return gq->get_matches(0, out, cap, n);
+}
+
+// ---- removeOutliers (+ bucketFeatures) on the device, stateless form ------------
+// n_lists match lists, list l = pm[l * stride .. + counts[l]).  max_features < 1: the vote only, out[l * out_cap ..] receives
+// the survivors; otherwise the survivors are bucketed as Matcher::bucketFeatures(max_features, bw, bh) does and out receives
+// the bucketed lists.  The group form (vh_group_post_begin_device) is the throughput path; this one exists for tests and timing.
+int32_t vh_remove_outliers_device(int32_t device, int32_t n_lists, const vh_p_match *pm, int64_t stride, const int32_t *counts, int32_t lanes_per_wave,
+                                  int32_t max_features, float bw, float bh, vh_p_match *out, int32_t out_cap, int32_t *out_counts,
+                                  int32_t *n_triangles, float *sweep_ms) {
+  if (n_lists < 1 || !counts || !out_counts || out_cap < 0 || (out_cap > 0 && !out) || stride < 0) return VH_ERR_INVALID_ARG;
+  if (max_features >= 1 && (!(bw >= 1) || !(bh >= 1))) return VH_ERR_INVALID_ARG;
+  int32_t cap = 4;
+  for (int32_t l = 0; l < n_lists; l++) {
+    if (counts[l] < 0 || counts[l] > stride) return VH_ERR_INVALID_ARG;
+    cap = std::max(cap, counts[l]);
+  }
+  if (cap > 1 && !pm) return VH_ERR_INVALID_ARG;
+  const int32_t rc = select_device(device);
+  if (rc) return rc;
+  VhVoteBuffers vb;
+  struct Guard { VhVoteBuffers &b; vh_p_match *src = nullptr; int32_t *cnt = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
+                 ~Guard() { b.release(); if (src) (void)hipFree(src); if (cnt) (void)hipFree(cnt); for (auto e : ev) if (e) (void)hipEventDestroy(e); } } gd{vb};
+  VH_HIP(vb.alloc(n_lists, cap, std::max(out_cap, 1)));
+  VH_HIP(vb.upload_lfsr());
+  VH_HIP(hipMalloc((void **)&gd.src, sizeof(vh_p_match) * (size_t)n_lists * cap));
+  VH_HIP(hipMalloc((void **)&gd.cnt, sizeof(int32_t) * (size_t)n_lists));
+  for (int32_t l = 0; l < n_lists; l++)
+    if (counts[l]) VH_HIP(hipMemcpy(gd.src + (size_t)l * cap, pm + (size_t)l * stride, sizeof(vh_p_match) * (size_t)counts[l], hipMemcpyHostToDevice));
+  VH_HIP(hipMemcpy(gd.cnt, counts, sizeof(int32_t) * (size_t)n_lists, hipMemcpyHostToDevice));
+  VH_HIP(hipEventCreate(&gd.ev[0])); VH_HIP(hipEventCreate(&gd.ev[1]));
+  vh_launch_vote_prep(vb.v, 0, n_lists, gd.src, cap, gd.cnt, cap, nullptr, 1, nullptr);
+  vh_launch_vote(vb.v, lanes_per_wave, max_features, bw, bh, vb.lfsr, vb.lfsr_n, vb.out, vb.out_cap, vb.out_count, gd.ev, nullptr);
+  VH_HIP(hipGetLastError());
+  VH_HIP(hipDeviceSynchronize());
+  if (sweep_ms) VH_HIP(hipEventElapsedTime(sweep_ms, gd.ev[0], gd.ev[1]));
+  std::vector<VhVoteMeta> meta((size_t)n_lists);
+  VH_HIP(hipMemcpy(meta.data(), vb.v.meta, sizeof(VhVoteMeta) * (size_t)n_lists, hipMemcpyDeviceToHost));
+  int32_t ret = VH_OK;
+  for (int32_t l = 0; l < n_lists; l++) {
+    const VhVoteMeta &m = meta[(size_t)l];
+    if (n_triangles) n_triangles[l] = m.ntri;
+    if (m.status == VH_VOTE_TRUNCATED) { out_counts[l] = max_features >= 1 ? m.out : m.kept; ret = VH_ERR_CAPACITY; continue; }
+    if (m.status != VH_VOTE_OK && m.status != VH_VOTE_SKIP) { out_counts[l] = 0; if (ret == VH_OK) ret = VH_ERR_UNSUPPORTED; continue; }
+    const int32_t k = max_features >= 1 ? m.out : m.kept;
+    out_counts[l] = k;
+    if (k > out_cap) { ret = VH_ERR_CAPACITY; continue; }
+    if (k > 0) VH_HIP(hipMemcpy(out + (size_t)l * out_cap, max_features >= 1 ? vb.out + (size_t)l * vb.out_cap : vb.v.pm + (size_t)l * cap,
+                                sizeof(vh_p_match) * (size_t)k, hipMemcpyDeviceToHost));
+  }
+  return ret;
 }
 
 }  // extern "C"

@@ -153,6 +153,19 @@ int32_t vh_remove_outliers(vh_matcher *m);
 /* The same on caller-owned records, in place, order preserved; *n_out = count
  * kept.  Pure host function: needs no device. */
 int32_t vh_remove_outliers_pm(vh_p_match *pm, int32_t n, int32_t *n_out);
+/* The same on the DEVICE for n_lists lists at once (csrc/kernels_vote.hip): list l = pm[l * stride .. + counts[l]).
+ * The triangulation under the vote stays the sequential chain it is (csrc/sweep_hull.h, the code the host form
+ * runs): one list per GPU lane, lanes_per_wave (1..64) lists per wavefront -- latency per list is tens of
+ * milliseconds, the throughput comes from the number of lists in flight (see vh_group_post_begin_device).
+ * max_features < 1: removeOutliers only, out[l * out_cap ..] receives list l's survivors in order;
+ * max_features >= 1: followed by Matcher::bucketFeatures(max_features, bucket_width, bucket_height)
+ * (src/matcher.cpp:140-187), out receives the bucketed lists.  out_counts[l]: records of list l in out;
+ * n_triangles (nullable): triangles of each list's triangulation; sweep_ms (nullable): device time of the
+ * sweep kernel.  VH_ERR_CAPACITY if a list does not fit out_cap; VH_ERR_UNSUPPORTED for lists the sweep
+ * refuses (NaN / infinite / negative coordinates, more than 257 flips pending). */
+int32_t vh_remove_outliers_device(int32_t device, int32_t n_lists, const vh_p_match *pm, int64_t stride, const int32_t *counts,
+                                  int32_t lanes_per_wave, int32_t max_features, float bucket_width, float bucket_height,
+                                  vh_p_match *out, int32_t out_cap, int32_t *out_counts, int32_t *n_triangles, float *sweep_ms);
 
 /* Matcher::bucketFeatures (src/matcher.h:132, src/matcher.cpp:140-187):
  * host-side post-processing of the current matches, LFSR shuffle included. */
@@ -372,6 +385,33 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
  * (VH_METHOD_FLOW or VH_METHOD_QUAD: both carry the left camera's flow). */
 int32_t vh_group_estimate_motion_mono(vh_group *g, const vh_mono_params *e, const int32_t *rand8, double *tr,
                                       int32_t *ok, int32_t *n_inliers);
+/* ---- the same chain ON THE DEVICE: no host work between matching and the pose (csrc/kernels_vote.hip) ----
+ * removeOutliers' Delaunay triangulation is a sequential chain per match list (csrc/sweep_hull.h); on the GPU a list
+ * takes tens of milliseconds as one lane, and the throughput comes from the lists in flight:
+ *   vh_group_post_device_config  steps_per_batch (1..64) steps are voted on by one kernel sequence (steps_per_batch * S
+ *                         lists), up to `batches` (1..64) such batches are in flight on low-priority streams beside the
+ *                         matcher's own kernels; lanes_per_wave (1..64) lists share a wavefront.  Default 4, 4, 1.
+ *                         VH_ERR_STATE while steps are in flight.
+ *   vh_group_post_begin_device   after vh_group_match_features: the step's S lists leave the matcher's buffer for the
+ *                         current batch (a device-to-device move; the matcher can go on at once); a full batch is launched:
+ *                         vote -> Matcher::bucketFeatures(max_features, bucket_width, bucket_height) (bucket sides >= 1 px)
+ *                         -> the stereo estimator (e, rand3[S][ransac_iters][3]) or the monocular one (mono,
+ *                         rand8[S][ransac_iters][8]) or neither.  want_lists: keep the bucketed lists for the finish call.
+ *                         All steps of a batch share one configuration (a different one closes the batch early).
+ *   vh_group_post_finish_device  the step begun `age` begins ago (0: the last): waits for its batch (launching it first if it
+ *                         is not full yet), then tr[S][6], ok[S], n_inliers[S] (with an estimator), counts[S] (nullable) and
+ *                         bucketed[S][cap_per_stream] (nullable; needs want_lists) as vh_group_post_finish.  A caller that
+ *                         finishes step t - steps_per_batch * (batches - 1) after beginning step t never waits for the vote.
+ *                         Every step begun must be finished before the ring of steps_per_batch * batches steps comes
+ *                         round (VH_ERR_STATE from the begin call otherwise).
+ * Results per stream are those of vh_group_post_finish: lists and flags bit for bit, tr to rounding. */
+int32_t vh_group_post_device_config(vh_group *g, int32_t steps_per_batch, int32_t batches, int32_t lanes_per_wave);
+int32_t vh_group_post_begin_device(vh_group *g, int32_t cap_per_stream, int32_t max_features, float bucket_width, float bucket_height,
+                                   const vh_ego_params *e, const int32_t *rand3, const vh_mono_params *mono, const int32_t *rand8,
+                                   int32_t want_lists);
+int32_t vh_group_post_finish_device(vh_group *g, int32_t age, double *tr, int32_t *ok, int32_t *n_inliers, vh_p_match *bucketed,
+                                    int32_t cap_per_stream, int32_t *counts);
+
 /* vh_group_post_finish with the MONOCULAR estimator as its last stage: what VisualOdometryMono::process runs
  * after the matching (src/viso_mono.cpp:34-37: bucketFeatures, then estimateMotion on the bucketed list; the
  * Delaunay vote before them is the tail of matchFeatures) for every stream of a group, flow or quad lists,

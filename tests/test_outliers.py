@@ -313,3 +313,123 @@ def test_gpu_pipelined_post_stage_matches_the_oracle_chain(pkg, ob, oracle, gpu)
         g.postFinish(0, 2, 50.0, 50.0)
     assert ex.value.code == pkg.VH_ERR_CAPACITY
     g.close()
+
+
+# ------------------------------------------------------------------ the vote on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [1, 3, 64])
+def test_device_vote_equals_the_reference_fixtures_and_the_oracle(lanes, pkg, oracle, gpu):
+    """vh_remove_outliers_device (csrc/kernels_vote.hip): the reference's own input/output vectors and random lists
+    -- among them empty, tiny, degenerate and duplicate-ridden ones -- in ONE batched launch, `lanes` lists per wave."""
+    z = golden()
+    rng = np.random.default_rng(21)
+    lists = [z[name + "__in"] for name in CASES]
+    want = [z[name + "__in"][z[name + "__kept"]] for name in CASES]
+    for n in (0, 1, 3, 4, 5, 17, 64, 65, 300, 1500, 2999):
+        pm = random_matches(pkg, rng, n) if n else np.zeros(0, pkg.P_MATCH_DTYPE)
+        lists.append(pm)
+        want.append(oracle.remove_outliers(pm)[0])
+    line = random_matches(pkg, rng, 12)
+    line["v1c"] = 50
+    line["u1c"] = np.arange(12) * 7
+    same = random_matches(pkg, rng, 9)
+    same["u1c"] = 33
+    same["v1c"] = 44
+    dup = random_matches(pkg, rng, 300)
+    dup["u1c"][100:110] = dup["u1c"][0:10]
+    dup["v1c"][100:110] = dup["v1c"][0:10]
+    for pm in (line, same, dup):
+        lists.append(pm)
+        want.append(oracle.remove_outliers(pm)[0])
+    got, ntri, _ = pkg.remove_outliers_device(lists, lanes_per_wave=lanes)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g.tobytes() == w.tobytes(), (k, len(lists[k]), len(g), len(w))
+    assert len(want[-3]) == 0 and len(want[-2]) == 0  # (nothing to triangulate: every match loses the vote)
+    # triangle counts of the reference-pinned triangulation
+    tri, _ = oracle.delaunay(np.stack([lists[0]["u1c"], lists[0]["v1c"]], 1))
+    assert ntri[0] == len(tri)
+    # ... followed by bucketFeatures on the device
+    got_b, _, _ = pkg.remove_outliers_device(lists, lanes_per_wave=lanes, max_features=3, bucket_width=40.0, bucket_height=30.0)
+    for k, (g, w) in enumerate(zip(got_b, want)):
+        assert g.tobytes() == oracle.bucket_features(w, 3, 40, 30).tobytes(), (k, len(g))
+
+
+@pytest.mark.gpu
+def test_device_vote_refuses_what_it_cannot_triangulate(pkg, gpu):
+    rng = np.random.default_rng(22)
+    pm = random_matches(pkg, rng, 50)
+    pm["u1c"][7] = np.nan
+    with pytest.raises(pkg.VisoHipError) as ex:
+        pkg.remove_outliers_device([pm])
+    assert ex.value.code == pkg.VH_ERR_UNSUPPORTED
+    neg = random_matches(pkg, rng, 50)
+    neg["u1c"][3] = -4  # the vote itself is defined; the bucket grid of a negative coordinate is not
+    assert len(pkg.remove_outliers_device([neg])[0][0]) <= 50
+    with pytest.raises(pkg.VisoHipError) as ex:
+        pkg.remove_outliers_device([neg], max_features=2)
+    assert ex.value.code == pkg.VH_ERR_UNSUPPORTED
+    with pytest.raises(pkg.VisoHipError) as ex:
+        pkg.remove_outliers_device([random_matches(pkg, rng, 400)], max_features=50, out_cap=20)
+    assert ex.value.code == pkg.VH_ERR_CAPACITY
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps_per_batch,batches,lanes", [(1, 2, 1), (2, 2, 2), (3, 2, 64)])
+def test_gpu_device_post_stage_matches_the_oracle_chain(steps_per_batch, batches, lanes, pkg, ob, oracle, gpu):
+    """vh_group_post_begin_device / vh_group_post_finish_device: removeOutliers -> bucketFeatures(2, 50, 50) -> stereo
+    estimateMotion entirely on the GPU, several steps in flight; per stream equal to the oracle's chain on the same quad
+    matches: bucketed lists bit for bit, inlier counts exact, tr to 1e-9."""
+    S, W, H, T = 3, 480, 200, 7
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, T, disparity=6 + s, blur=4, seed=400 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(T)] for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    g.postDeviceConfig(steps_per_batch, batches, lanes)
+    ge = pkg.EgoParams.default(f=400.0, cu=W / 2, cv=H / 2, base=0.5)
+    e = ob.EgoParams.default(f=400.0, cu=W / 2, cv=H / 2, base=0.5)
+    raw = np.random.default_rng(3).integers(0, 2 ** 31 - 1, (T, S, 200, 3)).astype(np.int32)
+    import ctypes as C
+
+    def want(t):
+        res = []
+        for s in range(S):
+            pm = oracle.matching(po, dims, 2, F[s][t - 1][0], F[s][t - 1][1], F[s][t][0], F[s][t][1])
+            pm, _ = oracle.remove_outliers(pm)
+            q = pm.copy()
+            n = oracle.lib.vo_bucket_features(q.ctypes.data_as(C.c_void_p), len(q), 2, C.c_float(50), C.c_float(50))
+            q = q[:n].copy()
+            res.append((q, oracle.estimate_motion_stereo(e, q, oracle.draw_samples(len(q), 200, raw[t, s].reshape(-1)))))
+        return res
+
+    def check(t, got):
+        for s, (q, (ok_o, tr_o, inl_o)) in enumerate(want(t)):
+            assert len(q) > 20 and got["lists"][s].tobytes() == q.tobytes(), (t, s)
+            assert got["ok"][s] == ok_o and got["n_inliers"][s] == len(inl_o), (t, s)
+            assert np.allclose(got["tr"][s], tr_o, rtol=1e-9, atol=1e-12), (t, s, got["tr"][s], tr_o)
+
+    with pytest.raises(pkg.VisoHipError):
+        g.postFinishDevice(0)  # nothing begun
+    depth = steps_per_batch * (batches - 1)
+    done = 0
+    for t in range(T):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+        if t == 0:
+            continue
+        g.matchFeatures(pkg.METHOD_QUAD)
+        g.postBeginDevice(8192, 2, 50.0, 50.0, ego=ge, rand3=raw[t], want_lists=True)
+        if t - depth >= 1:  # steps up to t are in flight; hand out step t - depth
+            check(t - depth, g.postFinishDevice(depth, want_lists=True))
+            done = t - depth
+    for t in range(done + 1, T):  # drain: the oldest first (a batch that is not full is launched by the first finish that needs it)
+        check(t, g.postFinishDevice(T - 1 - t, want_lists=True))
+    with pytest.raises(pkg.VisoHipError):
+        g.postFinishDevice(0)  # handed out already
+    # the device lists of the matcher are untouched by the post stage
+    assert g.getMatches(0).tobytes() == oracle.matching(po, dims, 2, F[0][T - 2][0], F[0][T - 2][1], F[0][T - 1][0], F[0][T - 1][1]).tobytes()
+    # a slot shorter than a list is reported
+    g.postBeginDevice(16, 2, 50.0, 50.0, ego=ge, rand3=raw[0])
+    with pytest.raises(pkg.VisoHipError) as ex:
+        g.postFinishDevice(0)
+    assert ex.value.code == pkg.VH_ERR_CAPACITY
+    g.close()

@@ -64,20 +64,41 @@ def free_port():
 
 
 def test_two_rank_launch_gloo(pkg):
-    """N>1 path on CPU: launched exactly as the driver launches bench.py, 2 ranks, gloo."""
+    """N>1 path on CPU: launched exactly as the driver launches bench.py, 2 ranks, gloo.  --dist-selftest runs
+    main()'s own multi-rank control flow (bench.RankProtocol: process group, gathered rank descriptions, fences,
+    timed blocks with the MAX-reduced clock and the agreed block count, final barrier) around a stubbed step:
+    rank r sleeps r + 1 ms per step, so rank 1 must set the clock."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-selftest", "--streams", "3", "--steps", "7"],
+         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-selftest", "--streams", "3", "--steps", "7", "--warmup", "2"],
         env=env, cwd=ROOT, stderr=subprocess.STDOUT, timeout=240).decode()
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out  # rank 0 only
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["global_stream_ids"] == [0, 1, 2, 3, 4, 5]  # disjoint rank-major sharding
     assert r["distinct_data"] is True
-    assert abs(r["max_rank_time"] - 0.1) < 1e-9 and r["wall"] >= 0.1  # the slowest rank sets the clock
-    assert r["value"] == pytest.approx(2 * 3 * 7 / 0.1)  # whole-job aggregate
+    # both ranks described themselves through the process group
+    assert sorted(x["rank"] for x in r["ranks_seen"]) == [0, 1] and len({x["uuid"] for x in r["ranks_seen"]}) == 2
+    # the agreed number of blocks (>= 3), each at least as long as the SLOWEST rank's 7 steps of 2 ms
+    assert r["blocks"]["count"] >= 3 and all(b >= 7 * 0.002 for b in r["blocks"]["seconds_each"])
+    assert 2.0 <= r["ms_per_step"] < 10.0
+    assert r["value"] == pytest.approx(2 * 3 * 7 / (r["ms_per_step"] * 7e-3))  # whole-job aggregate over the MAX-reduced clock
+
+
+def test_rank_protocol_single_process():
+    """The same protocol object with one rank and no process group (what `python bench.py` uses at N = 1)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    proto = bench.RankProtocol("gloo", 0, 0, 1)
+    assert proto.active is False and proto.gather({"rank": 0}) == [{"rank": 0}]
+    calls = []
+    blocks = proto.timed_blocks(lambda: calls.append(1), lambda: None, 5, 4)
+    assert len(blocks) == 4 and len(calls) == 20
+    proto.close()
+    with pytest.raises(AssertionError):
+        bench.check_ranks([{"rank": 0, "pci_bus_id": 1, "pci_device_id": 0, "uuid": "a"}, {"rank": 1, "pci_bus_id": 1, "pci_device_id": 0, "uuid": "a"}], 2)
 
 
 @pytest.mark.gpu
