@@ -42,7 +42,7 @@ WORKLOADS = {
                label="3840x2160 stereo quad-match, nms_n=3, 25x25 bins"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNELS = ("detect_nms", "emit_features", "bin_hist", "bin_scan", "bin_fill", "bin_sort",
+KERNELS = ("detect_nms", "count_chunks", "emit_features", "bin_hist", "bin_scan", "bin_fill", "bin_sort",
            "match", "chain", "emit_matches")
 
 

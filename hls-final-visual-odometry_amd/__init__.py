@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
     "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_clear_stream", "vh_group_stream_wait_images", "vh_group_profile_enable",
-    "vh_group_profile_read", "vh_group_profile_reset",
+    "vh_group_profile_read", "vh_group_profile_reset", "vh_group_debug_fail_next_alloc",
     "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion", "vh_group_search_stats",
     "vh_default_mono_params", "vh_estimate_motion_mono", "vh_group_estimate_motion_mono",
     "vh_group_post_begin", "vh_group_post_finish", "vh_group_post_finish_mono",
@@ -167,7 +167,7 @@ def _lib():
             "vh_group_synchronize": [vp], "vh_group_set_stream": [vp, vp], "vh_group_clear_stream": [vp],
             "vh_group_stream_wait_images": [vp, vp],
             "vh_group_profile_enable": [vp, i32], "vh_group_profile_read": [vp, C.c_char_p, vp, vp],
-            "vh_group_profile_reset": [vp],
+            "vh_group_profile_reset": [vp], "vh_group_debug_fail_next_alloc": [vp],
             "vh_estimate_motion_stereo": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
             "vh_group_estimate_motion": [vp, vp, vp, vp, vp, vp],
             "vh_estimate_motion_mono": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -528,6 +528,10 @@ class StreamGroup:
         sp = C.c_int32(0); rate = C.c_double(-1.0)
         _check(_lib().vh_group_search_stats(self._h, C.byref(sp), C.byref(rate)), "vh_group_search_stats")
         return bool(sp.value), rate.value
+
+    def debugFailNextAlloc(self):
+        """Test hook: the group's next device allocation fails once."""
+        _check(_lib().vh_group_debug_fail_next_alloc(self._h), "vh_group_debug_fail_next_alloc")
 
     def profileEnable(self, on: bool = True):
         _check(_lib().vh_group_profile_enable(self._h, 1 if on else 0), "vh_group_profile_enable")

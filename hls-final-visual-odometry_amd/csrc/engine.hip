@@ -111,6 +111,7 @@ struct Group {
   int32_t dims[3] = {0, 0, 0};
   VhGeom g{};
   VhSets sets{};
+  VhOrder order{};  // bin-ordered emission (vh_dev.h); order.enabled == 0: staging + bin_sort
   int32_t cap = 0, mcap = 0;
   int32_t pair_cur = 0;
   int64_t frames = 0;
@@ -203,7 +204,7 @@ struct Group {
     device_bytes = 0;
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0; ev_down_valid = false;
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
-    d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr;
+    d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr; order = VhOrder{};
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk2[0] = d_mchunk2[1] = nullptr; d_redo = nullptr;
     for (int k = 0; k < 2; k++) if (h_out[k]) { (void)hipHostFree(h_out[k]); h_out[k] = nullptr; d_out_mapped[k] = nullptr; }
     if (h_matches) { (void)hipHostFree(h_matches); h_matches = nullptr; d_matches_mapped = nullptr; }
@@ -226,6 +227,7 @@ struct Group {
   template <class T> int32_t dmalloc(T **out, size_t count, bool zero) {
     void *q = nullptr;
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (fail_next_alloc) { fail_next_alloc = false; t_last_error = "allocation failure requested by vh_group_debug_fail_next_alloc"; return VH_ERR_HIP; }
     VH_HIP(hipMalloc(&q, bytes));
     allocs.push_back(q);
     device_bytes += (int64_t)bytes;
@@ -274,6 +276,60 @@ struct Group {
     return VH_ERR_UNSUPPORTED;
   }
 
+  // Geometry of the bin-ordered emission (VhOrder): which v-bins and pixel rows each chunk of VH_CHUNK NMS blocks can
+  // touch, and -- the other way round -- which chunks can hold members of a v-bin / a pixel row.  Enabled when a
+  // chunk's counters fit the kernels' LDS tables; VH_ORDER=0 keeps the staging + bin_sort path (A/B runs, tests).
+  int32_t setup_order() {
+    order = VhOrder{};
+    static const bool off = [] { const char *e = getenv("VH_ORDER"); return e && e[0] == '0'; }();
+    if (off || g.nblocks <= 0 || sets.ubn < 1 || sets.vbn < 1) return VH_OK;
+    const int32_t n1 = g.n + 1, nch = g.nchunks, H = dims[1];
+    std::vector<int32_t> vbf(nch), vf(nch), vbl(nch), vl(nch);
+    int32_t VB = 1, VROW = 1;
+    for (int32_t k = 0; k < nch; k++) {
+      const int32_t b0 = k * VH_CHUNK, b1 = std::min(b0 + VH_CHUNK, g.nblocks) - 1;
+      vf[k] = ((b0 / g.nbx) * n1 + g.n + VH_MARGIN) * g.scale;             // smallest v of a feature of the chunk (full resolution)
+      vl[k] = ((b1 / g.nbx) * n1 + g.n + VH_MARGIN + g.n) * g.scale;       // largest
+      vbf[k] = std::min(vf[k] / sets.binsize, sets.vbn - 1);
+      vbl[k] = std::min(vl[k] / sets.binsize, sets.vbn - 1);
+      VB = std::max(VB, vbl[k] - vbf[k] + 1);
+      VROW = std::max(VROW, vl[k] - vf[k] + 1);
+    }
+    const int64_t nslot = 4 * (int64_t)sets.ubn * VB;
+    if (nslot > VH_ORDER_SLOTS_MAX || VROW > VH_ORDER_ROWS_MAX) return VH_OK;
+    std::vector<int32_t> bk0(sets.vbn, 1), bk1(sets.vbn, 0), rk0(H, 1), rk1(H, 0);
+    for (int32_t k = nch - 1; k >= 0; k--) {
+      for (int32_t vb = vbf[k]; vb <= vbl[k]; vb++) bk0[vb] = k;
+      for (int32_t v = vf[k]; v <= std::min(vl[k], H - 1); v++) rk0[v] = k;
+    }
+    for (int32_t k = 0; k < nch; k++) {
+      for (int32_t vb = vbf[k]; vb <= vbl[k]; vb++) bk1[vb] = k;
+      for (int32_t v = vf[k]; v <= std::min(vl[k], H - 1); v++) rk1[v] = k;
+    }
+    int32_t rc;
+    int32_t *d_tab = nullptr;
+    const size_t ntab = 2 * (size_t)nch + 2 * (size_t)sets.vbn + 2 * (size_t)H;
+    if ((rc = dmalloc(&d_tab, ntab, false))) return rc;
+    std::vector<int32_t> tab;
+    tab.insert(tab.end(), vbf.begin(), vbf.end()); tab.insert(tab.end(), vf.begin(), vf.end());
+    tab.insert(tab.end(), bk0.begin(), bk0.end()); tab.insert(tab.end(), bk1.begin(), bk1.end());
+    tab.insert(tab.end(), rk0.begin(), rk0.end()); tab.insert(tab.end(), rk1.begin(), rk1.end());
+    VH_HIP(hipMemcpy(d_tab, tab.data(), sizeof(int32_t) * ntab, hipMemcpyHostToDevice));
+    order.vb_first = d_tab; order.v_first = d_tab + nch;
+    order.bin_k0 = d_tab + 2 * nch; order.bin_k1 = order.bin_k0 + sets.vbn;
+    order.row_k0 = order.bin_k1 + sets.vbn; order.row_k1 = order.row_k0 + H;
+    order.VB = VB; order.VROW = VROW; order.nslot = (int32_t)nslot;
+    order.slot_bits = 1;
+    while ((1 << order.slot_bits) < order.nslot) order.slot_bits++;
+    const size_t nimg = 2 * (size_t)S;
+    if ((rc = dmalloc(&order.cbin, nimg * nch * (size_t)nslot, false))) return rc;
+    if ((rc = dmalloc(&order.crow, nimg * nch * 4 * (size_t)VROW, false))) return rc;
+    if ((rc = dmalloc(&order.cbase, nimg * ((size_t)nch + 1), true))) return rc;
+    if ((rc = dmalloc(&order.pos_of, 2 * VH_RING * (size_t)S * cap, false))) return rc;
+    order.enabled = 1;
+    return VH_OK;
+  }
+
   int32_t ensure(const int32_t d[3]) {
     if (allocated && d[0] == dims[0] && d[1] == dims[1] && d[2] == dims[2]) return VH_OK;
     if (allocated) { int32_t rs = sync_all(); if (rs) return rs; release(); }
@@ -315,7 +371,9 @@ struct Group {
     if ((rc = dmalloc(&sets.hist, ns * sets.nbins, true))) return rc;
     if ((rc = dmalloc(&sets.cursor, ns * sets.nbins, true))) return rc;
     if ((rc = dmalloc(&sets.tmp_idx, ns * cap, false))) return rc;
-    if ((rc = dmalloc(&sets.stage, ns * (size_t)sets.nbins * sets.stage_cap, false))) return rc;
+    if ((rc = setup_order())) return rc;
+    // (the per-bin staging lists are only needed when the features are not emitted in bin order: 2 MB per set at KITTI size)
+    if (!order.enabled && (rc = dmalloc(&sets.stage, ns * (size_t)sets.nbins * sets.stage_cap, false))) return rc;
     if ((rc = dmalloc(&sets.count, ns, true))) return rc;
     const size_t nrow = 4 * (size_t)dims[1];
     if ((rc = dmalloc(&sets.row_start, ns * (nrow + 1), true))) return rc;
@@ -384,9 +442,9 @@ struct Group {
   }
 
   // ---- detect + bin ------------------------------------------------------
-  int32_t zero_bin_counters(int32_t set0, int32_t nsets, int32_t *extra = nullptr, int64_t n_extra = 0) {
+  int32_t zero_bin_counters(int32_t set0, int32_t nsets, int32_t *extra = nullptr, int64_t n_extra = 0, bool light = false) {
     // one launch instead of a memset per array
-    vh_launch_zero_counters(sets, set0, nsets, extra, n_extra, stream);
+    vh_launch_zero_counters(sets, set0, nsets, extra, n_extra, light ? 1 : 0, stream);
     VH_HIP(hipGetLastError());
     return VH_OK;
   }
@@ -434,7 +492,7 @@ struct Group {
       VH_HIP(hipStreamWaitEvent(stream, ev_user, 0));
     }
     if (ev_read_valid[pair_cur]) VH_HIP(hipStreamWaitEvent(stream, ev_read[pair_cur], 0));
-    if ((rc = zero_bin_counters(set0, nsets, d_chunk_count, 2 * (int64_t)S * g.nchunks))) return rc;
+    if ((rc = zero_bin_counters(set0, nsets, d_chunk_count, 2 * (int64_t)S * g.nchunks, order.enabled != 0))) return rc;
     // The group is detected in up to four sub-batches of streams, one after the other on this
     // stream: the latency-bound kernels of a sub-batch (emit_features, bin_scan, bin_sort: < 45 %
     // of the VALU issue slots) then run beside the issue-bound ones of its neighbours and of the
@@ -465,9 +523,20 @@ struct Group {
         im.base[0] = half; im.base[1] = half + isz; im.stride = isz * ncam;
       }
       { Scope sc(this, "detect_nms", stream); vh_launch_detect_nms(im, g, rec, chunks, stream); }
-      { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, rec, chunks, sets, stream); }
-      VH_HIP(hipGetLastError());
-      if ((rc = bin_sets(set0 + 2 * s0, 2 * sn, true))) return rc;
+      if (order.enabled) {
+        // counts per chunk -> scan -> emission straight into bin order (no staging, no sort, no per-feature atomic)
+        VhOrder o = order;
+        const size_t i0 = (size_t)s0 * ncam;
+        o.cbin += i0 * g.nchunks * (size_t)o.nslot; o.crow += i0 * g.nchunks * 4 * (size_t)o.VROW; o.cbase += i0 * ((size_t)g.nchunks + 1);
+        { Scope sc(this, "count_chunks", stream); vh_launch_count_chunks(im, g, rec, sets, o, stream); }
+        { Scope sc(this, "bin_scan", stream); vh_launch_bin_scan_ordered(im, g, chunks, sets, o, set0 + 2 * s0, 2 * sn, stream); }
+        { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, rec, chunks, sets, o, stream); }
+        VH_HIP(hipGetLastError());
+      } else {
+        { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, rec, chunks, sets, order, stream); }
+        VH_HIP(hipGetLastError());
+        if ((rc = bin_sets(set0 + 2 * s0, 2 * sn, true))) return rc;
+      }
     }
     VH_HIP(hipEventRecord(ev_det[pair_cur], stream));
     return VH_OK;
@@ -550,9 +619,39 @@ struct Group {
     return false;
   }
 
+  // A match launch that failed half way leaves the emission's chunk counters and the re-search counters of its table
+  // buffer in an unknown state (each emission zeroes the OTHER buffer's counters for the next launch): the next
+  // match() puts both buffers back to zero before it queues anything.
+  bool match_dirty = false;
+  bool fail_next_alloc = false;  // test hook (vh_group_debug_fail_next_alloc)
+
+  int32_t match_recover() {
+    VH_HIP(hipStreamSynchronize(match_stream));
+    VH_HIP(hipStreamSynchronize(post_stream));
+    for (int k = 0; k < 2; k++) VH_HIP(hipMemset(d_mchunk2[k], 0, sizeof(int32_t) * (size_t)S * ((cap + 255) / 256)));
+    VH_HIP(hipMemset(d_redo, 0, sizeof(int32_t) * 2 * (size_t)S));
+    stats_pending[0] = stats_pending[1] = false;
+    last_method = -1;
+    match_dirty = false;
+    return VH_OK;
+  }
+
   int32_t match(int32_t method) {
     if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
     if (!allocated || failed) return VH_ERR_STATE;
+    if (match_dirty) { const int32_t rr = match_recover(); if (rr) return rr; }
+    // everything that can fail without a kernel of the step in flight comes first
+    bool fresh_mask = false;
+    if (method == VH_METHOD_FLOW && !d_mask) {
+      int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) { d_mask = nullptr; return rc; }
+      fresh_mask = true;
+    }
+    const int32_t rc = match_queued(method, fresh_mask);
+    if (rc) match_dirty = true;
+    return rc;
+  }
+
+  int32_t match_queued(int32_t method, bool fresh_mask) {
     const VhMatchArgs a = match_args(method);
     hipStream_t ms = match_stream, ps = post_stream;
     const int32_t buf = (int32_t)(match_seq++ & 1);
@@ -569,8 +668,7 @@ struct Group {
     VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
     int32_t *d_mchunk = d_mchunk2[buf];  // zeroed by the previous launch's emission (at allocation for the first two)
     if (method == VH_METHOD_FLOW) {
-      if (!d_mask) {
-        int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) return rc;
+      if (fresh_mask) {
         VH_HIP(hipMemsetAsync(d_mask, 0, sizeof(uint32_t) * (size_t)S * dims[0] * dims[1], ps));
         epoch = 0;
       }
@@ -1078,8 +1176,10 @@ struct Group {
       vstep.assign((size_t)vote_steps * vote_batches, VoteStep{});
       int prio_lo = 0, prio_hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      static const int prio_env = [] { const char *ev = getenv("VH_VOTE_STREAM_PRIO"); return ev ? atoi(ev) : 1; }();  // 1: lowest, 0: normal, -1: highest
+      const int prio = prio_env > 0 ? prio_lo : (prio_env < 0 ? prio_hi : 0);
       for (int k = 0; k < kVoteStreams; k++)
-        if (!vote_stream[k]) VH_HIP(hipStreamCreateWithPriority(&vote_stream[k], hipStreamNonBlocking, prio_lo));
+        if (!vote_stream[k]) VH_HIP(hipStreamCreateWithPriority(&vote_stream[k], hipStreamNonBlocking, prio));
       for (auto &b : vbatch) {
         VH_HIP(hipEventCreateWithFlags(&b.ev_prep, hipEventDisableTiming));
         VH_HIP(hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming));
@@ -1476,6 +1576,11 @@ int32_t vh_group_search_stats(vh_group *g, int32_t *speculative, double *researc
   Group *gq = (Group *)g; ENTER(gq);
   if (speculative) *speculative = gq->force_mode >= 0 ? gq->force_mode : (gq->spec_mode ? 1 : 0);
   if (research_rate) *research_rate = gq->last_redo_rate;
+  return VH_OK;
+}
+int32_t vh_group_debug_fail_next_alloc(vh_group *g) {
+  Group *gq = (Group *)g; ENTER(gq);
+  gq->fail_next_alloc = true;
   return VH_OK;
 }
 int32_t vh_group_profile_enable(vh_group *g, int32_t on) {

@@ -53,6 +53,9 @@ extern "C" int32_t vh_debug_flow_stats(unsigned long long *out, int32_t reset) {
 
 namespace {
 
+// features of a set that are in its bin order (the set's true count, s.count, can be larger: capacity)
+__device__ __forceinline__ int32_t indexed_count(const VhSets &s, int32_t set) { return s.bin_start[(int64_t)set * (s.nbins + 1) + s.nbins]; }
+
 __device__ __forceinline__ int32_t wave_min(int32_t v) {
 #pragma unroll
   for (int32_t d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
@@ -772,7 +775,7 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best, int32_t *__res
 __global__ void match_prior_kernel(VhSets s, VhMatchArgs a, double u_, double v_, int32_t *__restrict__ best) {
   const int32_t qset = vh_role_set(a.S, a.pair_cur, 0, a.pass[0].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, 0, a.pass[0].cset);
-  const int32_t nq = min(s.count[qset], s.cap);
+  const int32_t nq = indexed_count(s, qset);
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   const int32_t *q = s.feat + ((int64_t)qset * s.cap + i) * 12;
@@ -834,8 +837,8 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
   const int32_t stream = blockIdx.y;
   const int32_t set1p = vh_role_set(a.S, a.pair_cur, stream, 0), set2p = vh_role_set(a.S, a.pair_cur, stream, 1);
   const int32_t set1c = vh_role_set(a.S, a.pair_cur, stream, 2), set2c = vh_role_set(a.S, a.pair_cur, stream, 3);
-  const int32_t n1p = min(s.count[set1p], s.cap), n2p = min(s.count[set2p], s.cap);
-  const int32_t n1c = min(s.count[set1c], s.cap), n2c = min(s.count[set2c], s.cap);
+  const int32_t n1p = indexed_count(s, set1p), n2p = indexed_count(s, set2p);
+  const int32_t n1c = indexed_count(s, set1c), n2c = indexed_count(s, set2c);
   const int32_t *__restrict__ T = best + (int64_t)stream * 4 * s.cap;
   const int64_t cap = s.cap;
   // coordinates in reference order, 4 B per feature (the 48-byte records would cost a 64-byte sector per look-up)
@@ -888,7 +891,7 @@ __global__ void flow_keep_kernel(VhSets s, VhMatchArgs a, int4 *__restrict__ cha
                                  int32_t *__restrict__ mchunk, int32_t nchm) {
   const int32_t stream = blockIdx.y;
   const int32_t set1c = vh_role_set(a.S, a.pair_cur, stream, 2);
-  const int32_t n1c = min(s.count[set1c], s.cap);
+  const int32_t n1c = indexed_count(s, set1c);
   int4 *__restrict__ ch = chain + 2 * (int64_t)stream * s.cap;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n1c; i += gridDim.x * blockDim.x) {
     const int4 r = ch[2 * (int64_t)i];
@@ -921,7 +924,7 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
 #pragma unroll
   for (int32_t r = 0; r < 4; r++) sets[r] = vh_role_set(a.S, a.pair_cur, stream, r);
   const int32_t drive = (method == 2) ? sets[0] : sets[2];
-  const int32_t n = min(s.count[drive], s.cap);
+  const int32_t n = indexed_count(s, drive);
   if (chunk * 256 >= n && chunk != nchm - 1) return;
   const int4 *__restrict__ ch = chain + 2 * (int64_t)stream * s.cap;
   float *__restrict__ out = matches + (int64_t)stream * mcap * 12;
@@ -988,7 +991,7 @@ emit_matches_kernel(VhSets s, VhMatchArgs a, int32_t method, const int4 *__restr
     // statistics of this launch for the host's loop policy: queries searched again / queries searched
     int32_t nq = 0;
 #pragma unroll
-    for (int32_t k = 0; k < 4; k++) if (k < a.npass) nq += min(s.count[vh_role_set(a.S, a.pair_cur, stream, a.pass[k].qset)], s.cap);
+    for (int32_t k = 0; k < 4; k++) if (k < a.npass) nq += indexed_count(s, vh_role_set(a.S, a.pair_cur, stream, a.pass[k].qset));
     // count, overflow flag and the launch's statistics also go straight to host-mapped memory: the host reads
     // them after the launch's event instead of through small device->host copies (each a blit kernel + a round trip)
     host_out[stream] = make_int4(base + tot, ov, redo[stream], nq);

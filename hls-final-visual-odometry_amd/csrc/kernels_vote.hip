@@ -30,6 +30,7 @@
 #define VH_SH_DEVICE 1
 #include "sweep_hull.h"
 #include "vh_vote.h"
+#include <cstdlib>
 
 namespace {
 
@@ -229,9 +230,15 @@ __global__ __launch_bounds__(64) void vote_order_kernel(VhVote vt) {
 // `lanes` lists per wave, one per lane (the other lanes of the wave leave at once); the angular hash and the
 // flip stack of a lane's list live in LDS: lanes * (hsize + VH_VOTE_PEND) words of dynamic shared memory
 typedef __attribute__((address_space(3))) int32_t *LdsI32;
-__global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes) {
+__global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes, int32_t prio) {
   extern __shared__ int32_t sweep_lds[];
   const int32_t lane = threadIdx.x;
+  // a wave of this kernel lives for a hundred milliseconds beside thousands of short-lived ones of the matcher: with
+  // the default priority it gets one issue slot in eight on a busy SIMD and its latency -- the depth of the whole
+  // post-stage pipeline -- grows by as much
+  if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 1) __builtin_amdgcn_s_setprio(1);
   if (lane >= lanes) return;
   const int32_t p = blockIdx.x * lanes + lane;
   if (p >= vt.P) return;
@@ -400,7 +407,8 @@ void vh_launch_vote(const VhVote &vt, int32_t lanes, int32_t max_features, float
   lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
   hipLaunchKernelGGL(vote_order_kernel, dim3(vt.P), dim3(64), 0, st, vt);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[0], st);
-  hipLaunchKernelGGL(vote_sweep_kernel, dim3((vt.P + lanes - 1) / lanes), dim3(64), sizeof(int32_t) * (size_t)lanes * (vt.hsize + VH_VOTE_PEND), st, vt, lanes);
+  static const int32_t prio = [] { const char *e = getenv("VH_VOTE_PRIO"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(vote_sweep_kernel, dim3((vt.P + lanes - 1) / lanes), dim3(64), sizeof(int32_t) * (size_t)lanes * (vt.hsize + VH_VOTE_PEND), st, vt, lanes, prio);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[1], st);
   hipLaunchKernelGGL(vote_tally_kernel, dim3((2 * vt.cap + 255) / 256, vt.P), dim3(256), 0, st, vt);
   hipLaunchKernelGGL(vote_select_kernel, dim3(vt.P), dim3(64), 0, st, vt, max_features, bw, bh, lfsr, lfsr_n, out, out_cap, out_count);

@@ -428,6 +428,9 @@ int32_t vh_group_post_finish_mono(vh_group *g, int32_t age, int32_t max_features
  * (DESIGN.md section 4.1).  VH_FLOW_TESTED=1 / 0 in the environment pins the choice. */
 int32_t vh_group_search_stats(vh_group *g, int32_t *speculative, double *research_rate);
 
+/* Test hook: the next device allocation the group makes fails (VH_ERR_HIP), once.  Lets the suite drive the error
+ * paths of lazily allocated buffers (the flow method's pixel mask). */
+int32_t vh_group_debug_fail_next_alloc(vh_group *g);
 /* Kernel timing (HIP events recorded on the group's stream around every
  * kernel launch while enabled).  vh_group_profile_read returns the
  * accumulated milliseconds and launch count of kernel `name`

@@ -4,7 +4,9 @@
 // Chang-Tun-Yu/HLS-final-Visual-Odometry): nested `parameters` and `p_match`
 // with identical field order and layout, the constructor, setIntrinsics,
 // both pushBack overloads, matchFeatures, bucketFeatures and getMatches, all
-// with the reference's signatures and void returns.  src/viso.cpp,
+// with the reference's signatures and void returns -- plus computeFeatures,
+// the private member the reference's pushBack is built on (src/matcher.h:209),
+// with its signature and its _mm_malloc ownership.  src/viso.cpp,
 // src/viso_stereo.cpp and src/viso_mono.cpp therefore compile against this
 // header unchanged once it is on the include path AS "matcher.h"
 // (see INTEGRATION.md); `Matrix` only has to be a declared type, because
@@ -39,6 +41,7 @@
 #include <cstring>
 #include <iostream>
 #include <vector>
+#include <mm_malloc.h>  // _mm_malloc / _mm_free: the ownership contract of computeFeatures (src/matcher.h:208)
 
 #include "viso_hip.h"
 
@@ -88,7 +91,7 @@ class Matcher {
   };
 
   // constructor (src/matcher.cpp:32-41); `device` selects the GPU of this stream
-  explicit Matcher(parameters param, int32_t device = 0) : outlier_removal(true), param(param), handle(0) {
+  explicit Matcher(parameters param, int32_t device = 0) : outlier_removal(true), param(param), handle(0), device(device) {
     static_assert(sizeof(parameters) == sizeof(vh_params), "parameters must mirror vh_params");
     static_assert(sizeof(p_match) == sizeof(vh_p_match) && sizeof(p_match) == 48, "p_match must be 48 bytes");
     vh_params p;
@@ -146,6 +149,56 @@ class Matcher {
     return out;
   }
 
+  // src/matcher.h:209, src/matcher.cpp:585-672 -- the detector on one image, with the reference's signature and
+  // ownership: max1 / max2 (sparse set, only with param.multi_stage / dense set; 0 when empty) and the Sobel planes
+  // I_du, I_dv (at matching resolution: half size with param.half_resolution) are _mm_malloc blocks the CALLER
+  // releases with _mm_free; I_du_full / I_dv_full (the full-resolution planes) are produced only with
+  // param.half_resolution and left untouched otherwise, as the reference does (:606-613).  (A private member in
+  // the reference; public here, where nothing else calls it.)  The records are the reference's bit for bit; the
+  // planes agree with filter::sobel5x5 on the valid interior -- 2 pixels in from every edge -- outside of which
+  // the reference's SSE row passes hold wrapped-around values nothing reads.  On an error the
+  // outputs are 0 and a message goes to std::cerr.
+  void computeFeatures(uint8_t *I, const int32_t *dims, int32_t *&max1, int32_t &num1, int32_t *&max2, int32_t &num2,
+                       uint8_t *&I_du, uint8_t *&I_dv, uint8_t *&I_du_full, uint8_t *&I_dv_full) {
+    max1 = 0; max2 = 0; num1 = 0; num2 = 0; I_du = 0; I_dv = 0;
+    if (!I || !dims || dims[0] < 1 || dims[1] < 1 || dims[2] < dims[0]) { std::cerr << "ERROR: Image dimension mismatch!" << std::endl; return; }
+    vh_params p;
+    std::memcpy(&p, &param, sizeof(p));
+    int32_t dm[3] = {dims[0], dims[1], dims[2]};
+    if (param.half_resolution) {  // getHalfResolutionDimensions, src/matcher.cpp:566-570
+      dm[0] = dims[0] / 2; dm[1] = dims[1] / 2;
+      dm[2] = dm[0] > 0 ? dm[0] + 15 - (dm[0] - 1) % 16 : 16;
+    }
+    const size_t plane = (size_t)dm[2] * (size_t)dm[1], plane_full = (size_t)dims[2] * (size_t)dims[1];
+    // at most one feature per class and NMS block of (nms_n + 1)^2 pixels (src/matcher.cpp:381-466)
+    const int32_t blk = param.nms_n + 1;
+    const int64_t bound = std::max<int64_t>(4 * ((int64_t)dm[0] / blk + 1) * ((int64_t)dm[1] / blk + 1), 64);
+    std::vector<int32_t> t1, t2((size_t)bound * VH_FEATURE_WORDS);
+    if (param.multi_stage) t1.resize((size_t)bound * VH_FEATURE_WORDS);
+    uint8_t *du = (uint8_t *)_mm_malloc(std::max<size_t>(plane, 16), 16), *dv = (uint8_t *)_mm_malloc(std::max<size_t>(plane, 16), 16);
+    int32_t n1 = 0, n2 = 0;
+    int32_t rc = (du && dv) ? vh_compute_features(&p, device, I, dims, t1.empty() ? 0 : t1.data(), (int32_t)bound, &n1, t2.data(), (int32_t)bound, &n2, du, dv)
+                            : VH_ERR_CAPACITY;
+    uint8_t *duf = 0, *dvf = 0;
+    if (rc == VH_OK && param.half_resolution) {  // filter::sobel5x5 on the full-resolution image (:610-613)
+      duf = (uint8_t *)_mm_malloc(std::max<size_t>(plane_full, 16), 16); dvf = (uint8_t *)_mm_malloc(std::max<size_t>(plane_full, 16), 16);
+      rc = (duf && dvf) ? vh_filters(device, I, dims[2], dims[1], duf, dvf, 0, 0) : VH_ERR_CAPACITY;
+    }
+    int32_t *m1 = 0, *m2 = 0;
+    if (rc == VH_OK && n1 > 0) { m1 = (int32_t *)_mm_malloc(sizeof(int32_t) * VH_FEATURE_WORDS * (size_t)n1, 16); if (!m1) rc = VH_ERR_CAPACITY; }
+    if (rc == VH_OK && n2 > 0) { m2 = (int32_t *)_mm_malloc(sizeof(int32_t) * VH_FEATURE_WORDS * (size_t)n2, 16); if (!m2) rc = VH_ERR_CAPACITY; }
+    if (rc != VH_OK) {
+      report("computeFeatures", rc);
+      void *blocks[6] = {du, dv, duf, dvf, m1, m2};
+      for (int k = 0; k < 6; k++) if (blocks[k]) _mm_free(blocks[k]);
+      return;
+    }
+    if (m1) std::memcpy(m1, t1.data(), sizeof(int32_t) * VH_FEATURE_WORDS * (size_t)n1);
+    if (m2) std::memcpy(m2, t2.data(), sizeof(int32_t) * VH_FEATURE_WORDS * (size_t)n2);
+    max1 = m1; num1 = n1; max2 = m2; num2 = n2; I_du = du; I_dv = dv;
+    if (param.half_resolution) { I_du_full = duf; I_dv_full = dvf; }
+  }
+
   // The ring buffer's packed feature records {u,v,0,class,d1..d8}
   // (max2p/max2c of the reference, src/matcher.h:252); which = VH_SET_*.
   std::vector<int32_t> getFeatures(int32_t which) {
@@ -173,6 +226,7 @@ class Matcher {
   }
   parameters param;
   vh_matcher *handle;
+  int32_t device;
 };
 
 #endif  // VISO_HIP_MATCHER_HPP

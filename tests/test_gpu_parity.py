@@ -595,15 +595,42 @@ def test_index_invariants_on_the_checking_build(pkg, gpu):
     use unclamped -- row index -> bin position -> record, stage slots, winner positions
     (csrc/vh_dev.h: VH_CHECK_RANGE) -- and aborts the process on the first violation.  The parity
     cases that exercise those indices, the truncated-set case (features > capacity) among them,
-    must pass on it: same results, no violation."""
+    must pass on it: same results, no violation.  Every other test of this file runs on it (round 3: a subset)."""
     import subprocess, sys
     assert os.path.exists(pkg.CHECK_LIB_PATH), "build() makes it"
     env = dict(os.environ, VISO_HIP_LIB=pkg.CHECK_LIB_PATH)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                        "golden or random_configs or tie_break or ring_buffer or kitti or overflow or async_download or dims_change"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "not checking_build"],
+                       env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "VH_CHECK" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_failed_mask_allocation_leaves_the_group_usable(pkg, ob, oracle, gpu):
+    """The flow method allocates its pixel mask on first use.  If that allocation fails, the call fails BEFORE anything
+    of the step is queued -- the table buffers, the emission's chunk counters and the re-search counters keep their
+    state -- and the following matches (quad, then flow once memory is there) equal the oracle's."""
+    W, H, S = 320, 160, 2
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, 3, disparity=5 + s, blur=4, seed=90 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(3)] for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    for t in range(2):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+    g.matchFeatures(pkg.METHOD_QUAD)  # one ordinary launch first: the counters are in use
+    g.debugFailNextAlloc()
+    with pytest.raises(pkg.VisoHipError) as ex:
+        g.matchFeatures(pkg.METHOD_FLOW)
+    assert ex.value.code == pkg.VH_ERR_HIP
+    for rep in range(3):  # both table buffers come round
+        g.matchFeatures(pkg.METHOD_QUAD)
+        for s in range(S):
+            assert g.getMatches(s).tobytes() == oracle.matching(po, dims, 2, F[s][0][0], F[s][0][1], F[s][1][0], F[s][1][1]).tobytes()
+    g.matchFeatures(pkg.METHOD_FLOW)
+    for s in range(S):
+        assert g.getMatches(s).tobytes() == oracle.matching(po, dims, 0, m1p=F[s][0][0], m1c=F[s][1][0]).tobytes()
+    g.close()
 
 
 @pytest.mark.gpu

@@ -363,8 +363,9 @@ def test_device_vote_refuses_what_it_cannot_triangulate(pkg, gpu):
         pkg.remove_outliers_device([pm])
     assert ex.value.code == pkg.VH_ERR_UNSUPPORTED
     neg = random_matches(pkg, rng, 50)
-    neg["u1c"][3] = -4  # the vote itself is defined; the bucket grid of a negative coordinate is not
-    assert len(pkg.remove_outliers_device([neg])[0][0]) <= 50
+    neg["u1c"] -= 1000  # the vote itself is defined; the bucket grid of negative coordinates is not
+    neg["u1p"] -= 1000
+    assert 0 < len(pkg.remove_outliers_device([neg])[0][0]) <= 50
     with pytest.raises(pkg.VisoHipError) as ex:
         pkg.remove_outliers_device([neg], max_features=2)
     assert ex.value.code == pkg.VH_ERR_UNSUPPORTED
@@ -427,7 +428,12 @@ def test_gpu_device_post_stage_matches_the_oracle_chain(steps_per_batch, batches
         g.postFinishDevice(0)  # handed out already
     # the device lists of the matcher are untouched by the post stage
     assert g.getMatches(0).tobytes() == oracle.matching(po, dims, 2, F[0][T - 2][0], F[0][T - 2][1], F[0][T - 1][0], F[0][T - 1][1]).tobytes()
-    # a slot shorter than a list is reported
+    g.close()
+    # a slot shorter than a list is reported (cap_per_stream is what a fresh batch is sized by)
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    for t in range(2):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+    g.matchFeatures(pkg.METHOD_QUAD)
     g.postBeginDevice(16, 2, 50.0, 50.0, ego=ge, rand3=raw[0])
     with pytest.raises(pkg.VisoHipError) as ex:
         g.postFinishDevice(0)

@@ -162,3 +162,44 @@ def test_shim_mono_loop_matches_oracle(tmp_path, pkg, ob, oracle, gpu):
         want = oracle.bucket_features(want, 2, 50, 50)
         assert n == len(want) and n > 20 and got.tobytes() == want.tobytes()
     assert pos == len(raw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_default", "small_multi", "small_half", "small_multi_half_n3"])
+def test_shim_compute_features_member(name, tmp_path, pkg, ob, oracle, gpu):
+    """Matcher::computeFeatures of the drop-in header (src/matcher.h:209), called as oracle/ref_harness.cpp calls the
+    reference's -- references to null pointers in, _mm_malloc blocks out -- against the reference-generated fixtures:
+    sparse and dense records bit for bit, the Sobel planes on their valid interior (fixture hashes at matching
+    resolution; the oracle's filters for the full-resolution planes that half_resolution adds)."""
+    from conftest import load_golden
+    exe = str(tmp_path / "shim_compute_features")
+    subprocess.check_call(["g++", "-std=gnu++11", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_compute_features.cpp"), "-o", exe] + LINK)
+    p, dims, Ip, Ic, z = load_golden(name, pkg, pkg.Params)
+    W, H, bpl = dims
+    Ic.tofile(tmp_path / "img.bin")
+    subprocess.check_call([exe, str(tmp_path / "img.bin"), str(W), str(H), str(bpl), str(p.nms_n), str(p.nms_tau), str(p.multi_stage),
+                           str(p.half_resolution), str(tmp_path / "out.bin")], timeout=120)
+    raw = open(tmp_path / "out.bin", "rb").read()
+    pos = 0
+
+    def take(dtype, n):
+        nonlocal pos
+        a = np.frombuffer(raw, dtype, n, pos)
+        pos += a.nbytes
+        return a
+
+    n1 = int(take(np.int32, 1)[0]); m1 = take(np.int32, 12 * n1).reshape(n1, 12)
+    n2 = int(take(np.int32, 1)[0]); m2 = take(np.int32, 12 * n2).reshape(n2, 12)
+    dm = take(np.int32, 3)
+    du = take(np.uint8, int(dm[2]) * int(dm[1])).reshape(dm[1], dm[2]); dv = take(np.uint8, int(dm[2]) * int(dm[1])).reshape(dm[1], dm[2])
+    has_full = int(take(np.int32, 1)[0])
+    assert np.array_equal(m2, z["max2c"]) and np.array_equal(m1, z["max1c"]) and n2 > 100
+    assert (n1 > 0) == bool(p.multi_stage) and has_full == int(bool(p.half_resolution))
+    assert oracle.fnv(np.ascontiguousarray(du[2:-2, 2:du.shape[1] - 16])) == int(z["du_interior_fnv"])
+    assert oracle.fnv(np.ascontiguousarray(dv[2:-2, 2:dv.shape[1] - 16])) == int(z["dv_interior_fnv"])
+    if has_full:
+        duf = take(np.uint8, bpl * H).reshape(H, bpl); dvf = take(np.uint8, bpl * H).reshape(H, bpl)
+        odu, odv, _, _ = oracle.filters(Ic)
+        assert np.array_equal(duf[2:-2, 2:W - 2], odu[2:-2, 2:W - 2]) and np.array_equal(dvf[2:-2, 2:W - 2], odv[2:-2, 2:W - 2])
+    assert pos == len(raw)
