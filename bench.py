@@ -301,10 +301,11 @@ def main():
     ap.add_argument("--noise-frac", type=float, default=1.0, help="context runs: share of the pixels that receive --noise")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the as-shipped-loop measurement (e2e_matchfeatures)")
+    ap.add_argument("--no-flow", action="store_true", help="skip the reference-pinned mono flow workload (flow_pinned)")
     ap.add_argument("--no-e2e-host", action="store_true", help="skip the host-vote form of the as-shipped loop")
-    ap.add_argument("--e2e-steps-per-batch", type=int, default=int(os.environ.get("VH_E2E_STEPS_PER_BATCH", "4")))
+    ap.add_argument("--e2e-steps-per-batch", type=int, default=int(os.environ.get("VH_E2E_STEPS_PER_BATCH", "32")))
     ap.add_argument("--e2e-batches", type=int, default=int(os.environ.get("VH_E2E_BATCHES", "4")))
-    ap.add_argument("--e2e-lanes", type=int, default=int(os.environ.get("VH_E2E_LANES", "1")))
+    ap.add_argument("--e2e-lanes", type=int, default=int(os.environ.get("VH_E2E_LANES", "64")))
     ap.add_argument("--e2e-steps", type=int, default=0, help="steps of the device e2e loop (0: 4 x the steps in flight, at least 48)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",
@@ -391,12 +392,12 @@ def main():
     # per-kernel device time: the same loop once more with HIP events recorded around every
     # launch on the stream it is launched on (two internal streams: detect of frame t+1 overlaps
     # match of frame t, so these durations include what the other stream does to the kernel)
-    def profiled(group, n, kk):
+    def profiled(group, n, kk, mono=False):
         group.profileReset(); group.profileEnable(True)
         for _ in range(n):
             tq = kk % T
-            group.pushBackDevice(frames[tq, 0].data_ptr(), frames[tq, 1].data_ptr(), stride, dims, False)
-            group.matchFeatures(pkg.METHOD_QUAD)
+            group.pushBackDevice(frames[tq, 0].data_ptr(), None if mono else frames[tq, 1].data_ptr(), stride, dims, False)
+            group.matchFeatures(pkg.METHOD_FLOW if mono else pkg.METHOD_QUAD)
             kk += 1
         group.synchronize(); torch.cuda.synchronize()
         group.profileEnable(False)
@@ -478,6 +479,60 @@ def main():
                         "host_threads": nthr, "host_ms_per_step_vote_and_bucket": float(np.median(host_ms)),
                         "bucketed_matches_per_stream": float(r["counts"].mean()), "pose_ok_share": float(np.mean(ok_share)),
                         "bound": "host: the Delaunay vote of removeOutliers is a sequential float triangulation per stream (csrc/outliers.cpp)"}
+    # ---- the reference-pinned workload (a context key): what VisualOdometryMono::process runs (src/viso_mono.cpp:33-39) --
+    # pushBack of ONE camera + matchFeatures(0), flow matching being the only composition the reference implements
+    # (src/matcher.cpp:308-336).  Same S streams, same frames (left camera); after the timing stream 0's first frame pair,
+    # which is SURVEY Appendix B's pair, is matched once more on its own and compared with the reference's known answers.
+    flow = None
+    if not args.no_flow and args.workload == "kitti" and world == 1:
+        gf = pkg.StreamGroup(S, pkg.Params.default(**wl["params"]), device=local_rank, max_features=wl["cap"], max_matches=wl["cap"])
+        gf.setStream(stream.cuda_stream)
+        kf = 0
+
+        def fstep():
+            nonlocal kf
+            gf.pushBackDevice(frames[kf % T, 0].data_ptr(), None, stride, dims, False)
+            gf.matchFeatures(pkg.METHOD_FLOW)
+            kf += 1
+
+        def ffence():
+            gf.synchronize(); torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            fstep()
+        ffence()
+        fb = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fstep()
+            ffence()
+            fb.append(time.perf_counter() - t0)
+        fdt = float(np.median(fb))
+        fprof = profiled(gf, min(args.steps, 12), kf, mono=True)
+        kf += min(args.steps, 12)
+        fnf, fnm = gf.getCounts()
+        fq = [gf.getFeatures(0, w_) for w_ in (0, 2)]  # stream 0: previous / current left features of the last step
+        pairs_f = 2 * in_window_pairs(fq[1], fq[0], pkg.Params.default(**wl["params"]).match_radius)  # both passes walk the same in-window pairs
+        gf.close()
+        fsec = fprof["match"]["us_per_launch"] * 1e-6 if "match" in fprof else None
+        known = np.load(os.path.join(ROOT, "tests", "golden", "known_answers.npz"))
+        m1 = pkg.Matcher(pkg.Params.default(**wl["params"]), outlier_removal=False)
+        m1.pushBack(frames_np[0, 0, 0], None, dims, False)
+        m1.pushBack(frames_np[1, 0, 0], None, dims, False)
+        m1.matchFeatures(pkg.METHOD_FLOW)
+        pm1 = m1.getMatches()
+        m1.close()
+        flow = {"metric": "mono frames/sec (detect 1 image + flow match), KITTI 1241x376: the composition the reference implements (src/matcher.cpp:308-336)",
+                "value": S * args.steps / fdt, "unit": "frames/s", "ms_per_step": 1e3 * fdt / args.steps, "blocks_s": [round(b, 5) for b in fb],
+                "features_per_image": float(fnf.astype(np.float64)[:, 2].mean()), "matches_per_frame": float(fnm.mean()),
+                "kernels_us_per_launch": {n_: round(v["us_per_launch"], 2) for n_, v in fprof.items()},
+                "valu_sad": None if not fsec else {"achieved": pairs_f * 8 / 64 * S / fsec, "peak_measured": 5.26e11, "frac": pairs_f * 8 / 64 * S / fsec / 5.26e11,
+                                                   "in_window_pairs_per_frame": pairs_f},
+                "known_answer": {"source": "SURVEY Appendix B / tests/golden/known_answers.npz (generated by the reference's own build)",
+                                 "matches": int(len(pm1)), "matches_expected": int(known["kitti_1241x376__n_match"]),
+                                 "fnv_p_match": "%016x" % pkg.synth.fnv1a64(pm1), "fnv_expected": "%016x" % int(known["kitti_1241x376__fnv_p_match"])}}
+        flow["known_answer"]["ok"] = bool(flow["known_answer"]["matches"] == flow["known_answer"]["matches_expected"] and
+                                          flow["known_answer"]["fnv_p_match"] == flow["known_answer"]["fnv_expected"])
     search_spec, search_redo = grp.searchStats()
     nf, nm = grp.getCounts()
     wl_radius = pkg.Params.default(**wl["params"]).match_radius
@@ -563,6 +618,7 @@ def main():
             # detection runs in sub-batches of streams (engine.hip): several launches per step
             "kernels_launches_per_step": {n_: round(v["launches"] / args.steps, 2) for n_, v in prof.items()},
             "kernels_us_per_launch_exclusive": {n_: round(v["us_per_launch"], 2) for n_, v in prof_excl.items()},
+            "flow_pinned": flow,
             "e2e_matchfeatures": e2e,
             "e2e_matchfeatures_host_vote": e2e_host,
             "parity_scope": "primitives (computeFeatures, createIndexVector, findMatch, flow matching) pinned to the reference; "

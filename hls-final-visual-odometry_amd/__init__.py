@@ -298,10 +298,12 @@ class Matcher:
 
     def getMatches(self) -> np.ndarray:
         n = C.c_int32(0)
-        _check(_lib().vh_get_matches(self._h, None, 0, C.byref(n)), "vh_get_matches", allow=(VH_ERR_CAPACITY,))
+        rc = _check(_lib().vh_get_matches(self._h, None, 0, C.byref(n)), "vh_get_matches", allow=(VH_ERR_CAPACITY,))
         out = np.zeros(n.value, P_MATCH_DTYPE)
         if n.value:
             _check(_lib().vh_get_matches(self._h, _ptr(out), n.value, C.byref(n)), "vh_get_matches")
+        elif rc != VH_OK:  # an empty list from truncated feature sets is still an error
+            raise VisoHipError(rc, "vh_get_matches")
         return out
 
     def getFeatures(self, which: int) -> np.ndarray:
@@ -379,11 +381,13 @@ class StreamGroup:
 
     def getMatches(self, stream: int) -> np.ndarray:
         n = C.c_int32(0)
-        _check(_lib().vh_group_get_matches(self._h, stream, None, 0, C.byref(n)), "vh_group_get_matches",
-               allow=(VH_ERR_CAPACITY,))
+        rc = _check(_lib().vh_group_get_matches(self._h, stream, None, 0, C.byref(n)), "vh_group_get_matches",
+                    allow=(VH_ERR_CAPACITY,))
         out = np.zeros(n.value, P_MATCH_DTYPE)
         if n.value:
             _check(_lib().vh_group_get_matches(self._h, stream, _ptr(out), n.value, C.byref(n)), "vh_group_get_matches")
+        elif rc != VH_OK:
+            raise VisoHipError(rc, "vh_group_get_matches")
         return out
 
     def getFeatures(self, stream: int, which: int) -> np.ndarray:

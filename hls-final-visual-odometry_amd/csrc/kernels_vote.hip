@@ -191,8 +191,15 @@ __global__ __launch_bounds__(64) void vote_order_kernel(VhVote vt) {
   }
   const int32_t s0 = (int32_t)(uint32_t)best;
   uint2 *sorted = wave_radix_sort(buf_a, buf_b, n, hist, base);
+  // the points leave in visiting order: the sweep numbers them by their rank (vt.spts), vt.order maps a rank back to the
+  // match it came from (the tally votes by match)
   int32_t *order = vt.order + (int64_t)p * vt.cap;
-  for (int32_t i = lane; i < n; i += 64) order[i] = (int32_t)sorted[i].y;
+  float2 *spts = vt.spts + (int64_t)p * vt.cap;
+  for (int32_t i = lane; i < n; i += 64) {
+    const int32_t src = (int32_t)sorted[i].y;
+    order[i] = src;
+    spts[i] = pts[src];
+  }
   // :240-262 the seed triangle: nearest point to the first, then the smallest circumcircle
   const float2 q0 = pts[s0];
   best = ~0ull;
@@ -223,7 +230,17 @@ __global__ __launch_bounds__(64) void vote_order_kernel(VhVote vt) {
     best = wave_min_u64(best);
     if (best != ~0ull) s2 = (int32_t)(uint32_t)best;
   }
-  if (lane == 0) { m.seeds[0] = s0; m.seeds[1] = s1; m.seeds[2] = s2; m.span = span; }
+  // the seeds' ranks
+  int32_t r0 = kNone, r1 = kNone, r2 = kNone;
+  for (int32_t i = lane; i < n; i += 64) {
+    const int32_t src = (int32_t)sorted[i].y;
+    if (src == s0) r0 = i;
+    if (src == s1) r1 = i;
+    if (src == s2) r2 = i;
+  }
+#pragma unroll
+  for (int32_t d = 32; d >= 1; d >>= 1) { r0 = max(r0, __shfl_xor(r0, d)); r1 = max(r1, __shfl_xor(r1, d)); r2 = max(r2, __shfl_xor(r2, d)); }
+  if (lane == 0) { m.seeds[0] = r0; m.seeds[1] = s1 == kNone ? kNone : r1; m.seeds[2] = s2 == kNone ? kNone : r2; m.span = span; }
 }
 
 // ---- vote_sweep --------------------------------------------------------------------------------------
@@ -250,8 +267,8 @@ __global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes
   sw.bucket = (LdsI32)(sweep_lds + lane * (vt.hsize + VH_VOTE_PEND));
   sw.pend = sw.bucket + vt.hsize;
   sw.pend_cap = VH_VOTE_PEND;
-  sw.pts = (const Pt *)(vt.pts + (int64_t)p * vt.cap);
-  sw.order = vt.order + (int64_t)p * vt.cap;
+  sw.pts = (const Pt *)(vt.spts + (int64_t)p * vt.cap);
+  sw.order = nullptr;  // (numbered in visiting order by vote_order)
   sw.n = m.n;
   if (sw.seed(m.seeds[0], m.seeds[1], m.seeds[2], m.span)) sw.insert_all();
   m.ntri = sw.ntri;
@@ -268,7 +285,8 @@ __global__ __launch_bounds__(256) void vote_tally_kernel(VhVote vt) {
   const int32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= m.ntri) return;
   const vh_sh::Half *T = vt.half + ((int64_t)p * 2 * vt.cap + t) * 4;
-  const int32_t a = T[0].p, b = T[1].p, c = T[2].p;
+  const int32_t *order = vt.order + (int64_t)p * vt.cap;
+  const int32_t a = order[T[0].p], b = order[T[1].p], c = order[T[2].p];  // corner ranks -> matches
   const float2 *flow = vt.flow + (int64_t)p * vt.cap;
   const float2 fa = flow[a], fb = flow[b], fc = flow[c];
   const float tol = 5;  // hard-coded in the reference (:34), not parameters::outlier_flow_tolerance
@@ -407,7 +425,7 @@ void vh_launch_vote(const VhVote &vt, int32_t lanes, int32_t max_features, float
   lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
   hipLaunchKernelGGL(vote_order_kernel, dim3(vt.P), dim3(64), 0, st, vt);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[0], st);
-  static const int32_t prio = [] { const char *e = getenv("VH_VOTE_PRIO"); return e ? atoi(e) : 0; }();
+  static const int32_t prio = [] { const char *e = getenv("VH_VOTE_PRIO"); return e ? atoi(e) : 3; }();
   hipLaunchKernelGGL(vote_sweep_kernel, dim3((vt.P + lanes - 1) / lanes), dim3(64), sizeof(int32_t) * (size_t)lanes * (vt.hsize + VH_VOTE_PEND), st, vt, lanes, prio);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[1], st);
   hipLaunchKernelGGL(vote_tally_kernel, dim3((2 * vt.cap + 255) / 256, vt.P), dim3(256), 0, st, vt);

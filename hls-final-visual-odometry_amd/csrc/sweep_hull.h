@@ -110,7 +110,10 @@ struct Sweep {
   FastI32 pend;
   int32_t pend_cap;
   const Pt *pts;
-  const int32_t *order;  // the visiting order: ascending distance from the bounding box's centre, stable (:192-232, :409-424)
+  // the visiting order: ascending distance from the bounding box's centre, stable (:192-232, :409-424); null: the points
+  // are numbered in visiting order already (the device build: the hull's nodes are then the most recently visited
+  // points, neighbours in memory, instead of being scattered over the whole node array)
+  const int32_t *order;
   int32_t n;
   // state
   int32_t ntri;        // triangles emitted
@@ -261,12 +264,12 @@ struct Sweep {
 
   // :303-404; the three seeds are offered to the hull like every other point
   VH_SH_FN void insert_all() {
-    int32_t i_next = n > 0 ? order[0] : 0;
+    int32_t i_next = n > 0 ? (order ? order[0] : 0) : 0;
     Pt q_next = n > 0 ? pts[i_next] : Pt{0, 0};
     for (int32_t k = 0; k < n; k++) {
       const int32_t i = i_next;
       const Pt q = q_next;
-      if (k + 1 < n) { i_next = order[k + 1]; q_next = pts[i_next]; }  // (requested a whole insertion ahead of its use)
+      if (k + 1 < n) { i_next = order ? order[k + 1] : k + 1; q_next = pts[i_next]; }  // (requested a whole insertion ahead of its use)
       int32_t at = kNone;
       Node N{};
       const int32_t first = bucket_of(q);

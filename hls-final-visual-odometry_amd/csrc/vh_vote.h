@@ -31,6 +31,7 @@ struct VhVote {
   int32_t hsize;           // hash_size(cap)
   vh_p_match *pm;          // [P][cap] the lists, compacted in place by vote_select
   float2 *pts, *flow;      // [P][cap] (u1c, v1c) / (u1c - u1p, v1c - v1p)
+  float2 *spts;            // [P][cap] the points in visiting order (the sweep's numbering)
   int32_t *votes, *order;  // [P][cap]
   vh_sh::Node *node;       // [P][cap]
   vh_sh::Half *half;       // [P][8 cap] half-edge records, four slots per triangle; before the sweep the sort's ping-pong buffers, after the tally the bucketing's scratch
@@ -75,10 +76,10 @@ struct VhVoteBuffers {
     const int32_t hs = vh_sh::hash_size(cap);
     const auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t n = (size_t)P * (size_t)cap;
-    const size_t sz[11] = {n * 48, n * 8, n * 8, n * 4, n * 4, n * sizeof(vh_sh::Node), 8 * n * sizeof(vh_sh::Half),
-                           (size_t)P * sizeof(VhVoteMeta), (size_t)P * (size_t)out_cap_ * 48, (size_t)P * 4, (size_t)cap * 4};
-    size_t off[11], total = 0;
-    for (int k = 0; k < 11; k++) { off[k] = total; total += up(sz[k]); }
+    const size_t sz[12] = {n * 48, n * 8, n * 8, n * 4, n * 4, n * sizeof(vh_sh::Node), 8 * n * sizeof(vh_sh::Half),
+                           (size_t)P * sizeof(VhVoteMeta), (size_t)P * (size_t)out_cap_ * 48, (size_t)P * 4, (size_t)cap * 4, n * 8};
+    size_t off[12], total = 0;
+    for (int k = 0; k < 12; k++) { off[k] = total; total += up(sz[k]); }
     const hipError_t e = hipMalloc((void **)&block, total);
     if (e != hipSuccess) { block = nullptr; return e; }
     bytes = total;
@@ -89,6 +90,7 @@ struct VhVoteBuffers {
     v.meta = (VhVoteMeta *)(block + off[7]);
     out = (vh_p_match *)(block + off[8]); out_count = (int32_t *)(block + off[9]); out_cap = out_cap_;
     lfsr = (uint32_t *)(block + off[10]); lfsr_n = cap;
+    v.spts = (float2 *)(block + off[11]);
     return hipSuccess;
   }
   // the table of draws; the copy is synchronous (pageable source)
