@@ -1107,7 +1107,7 @@ struct Group {
   // 4x5 10.4, 8x5 11.7, 16x5 19.9, 32x3 25.3, 32x4 30.4, 48x3 30.2, 64x3 33.9; 1 list per wave, 4x5: 17.9.  A batch takes
   // 0.4-0.5 s from launch to results whatever its size (profiles/r04_vote_trace.txt): the rate is the number of steps in
   // flight over that latency, and a wave of 64 lists costs the chip 1/14 of what 64 single-list waves cost.
-  int32_t vote_steps = 32, vote_batches = 4, vote_lanes = 64;
+  int32_t vote_steps = 64, vote_batches = 3, vote_lanes = 64;
   int64_t post_dev_seq = 0;   // steps begun
   int32_t vote_cur = 0;       // batch receiving steps
   struct VoteStep { int32_t batch = -1, pos = 0; bool open = false; };
@@ -1132,11 +1132,12 @@ struct Group {
   }
 
   // bucket grid of Matcher::bucketFeatures on this group's images: floor(u_max / bw) + 1 columns, floor(v_max / bh) + 1 rows (matcher.cpp:150-151)
-  int32_t bucket_need(int32_t max_features, float bw, float bh, int64_t *need) const {
+  int32_t bucket_need(int32_t max_features, float bw, float bh, int64_t *need, int64_t *grid = nullptr) const {
     if (max_features < 1 || !(bw >= 1) || !(bh >= 1)) return VH_ERR_INVALID_ARG;
     const int64_t cols = (int64_t)floorf((float)(dims[0] - 1) / bw) + 1, rows = (int64_t)floorf((float)(dims[1] - 1) / bh) + 1;
     if (cols * rows > (1 << 20)) return VH_ERR_UNSUPPORTED;
     *need = std::min<int64_t>(cols * rows * max_features, mcap);
+    if (grid) *grid = cols * rows;
     return VH_OK;
   }
 
@@ -1171,8 +1172,8 @@ struct Group {
     if (!allocated || last_method < 0) return VH_ERR_STATE;
     if (e && last_method != VH_METHOD_QUAD) return VH_ERR_STATE;        // the stereo estimator needs both cameras of both frames
     if (mono && last_method == VH_METHOD_STEREO) return VH_ERR_STATE;   // the monocular one the left camera of both frames
-    int64_t need = 0;
-    int32_t rc = bucket_need(max_features, bw, bh, &need);
+    int64_t need = 0, grid = 0;
+    int32_t rc = bucket_need(max_features, bw, bh, &need, &grid);
     if (rc) return rc;
     cap_ps = std::min(cap_ps, mcap);
     if (vbatch.empty()) {
@@ -1208,9 +1209,9 @@ struct Group {
       }
       b->steps = 0; b->launched = false; b->busy = false; b->handed = 0;
       const int32_t P = vote_steps * S;
-      if (b->vb.v.cap < cap_ps || b->vb.out_cap < need || b->vb.v.P < P) {
+      if (b->vb.v.cap < cap_ps || b->vb.out_cap < need || b->vb.v.P < P || b->vb.v.nb_max < grid) {
         b->vb.release();
-        VH_HIP(b->vb.alloc(P, cap_ps, (int32_t)need));
+        VH_HIP(b->vb.alloc(P, cap_ps, (int32_t)need, (int32_t)grid));
         VH_HIP(b->vb.upload_lfsr());
       }
       const int32_t ocap = b->vb.out_cap;
@@ -2038,7 +2039,20 @@ int32_t vh_remove_outliers_device(int32_t device, int32_t n_lists, const vh_p_ma
   VhVoteBuffers vb;
   struct Guard { VhVoteBuffers &b; vh_p_match *src = nullptr; int32_t *cnt = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
                  ~Guard() { b.release(); if (src) (void)hipFree(src); if (cnt) (void)hipFree(cnt); for (auto e : ev) if (e) (void)hipEventDestroy(e); } } gd{vb};
-  VH_HIP(vb.alloc(n_lists, cap, std::max(out_cap, 1)));
+  // the bucket grid these lists can need (matcher.cpp:150-151: floor(u_max / bw) + 1 columns, floor(v_max / bh) + 1 rows)
+  int64_t grid = 1;
+  if (max_features >= 1) {
+    float u_max = 0, v_max = 0;
+    for (int32_t l = 0; l < n_lists; l++)
+      for (int32_t i = 0; i < counts[l]; i++) {
+        const vh_p_match &q = pm[(size_t)l * stride + i];
+        if (q.u1c > u_max) u_max = q.u1c;
+        if (q.v1c > v_max) v_max = q.v1c;
+      }
+    grid = ((int64_t)floorf(u_max / bw) + 1) * ((int64_t)floorf(v_max / bh) + 1);
+    if (!(grid >= 1) || grid > (1 << 20)) return VH_ERR_UNSUPPORTED;
+  }
+  VH_HIP(vb.alloc(n_lists, cap, std::max(out_cap, 1), (int32_t)grid));
   VH_HIP(vb.upload_lfsr());
   VH_HIP(hipMalloc((void **)&gd.src, sizeof(vh_p_match) * (size_t)n_lists * cap));
   VH_HIP(hipMalloc((void **)&gd.cnt, sizeof(int32_t) * (size_t)n_lists));

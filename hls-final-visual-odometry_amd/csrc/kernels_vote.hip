@@ -343,11 +343,10 @@ __global__ __launch_bounds__(64) void vote_select_kernel(VhVote vt, int32_t max_
   }
   const int32_t cols = (int32_t)floorf(u_max / bw) + 1, rows = (int32_t)floorf(v_max / bh) + 1;
   const int64_t nb64 = (int64_t)cols * rows;
-  // scratch in the triangle storage (the tally is over): pairs a | pairs b | per bucket {start, shuffle offset, out offset}
+  // the sort's ping-pong buffers in the half-edge storage (the tally is over); per bucket {start, shuffle offset, out offset}
   uint2 *buf_a = (uint2 *)(vt.half + (int64_t)p * 8 * vt.cap), *buf_b = buf_a + vt.cap;
-  int32_t *bstart = (int32_t *)(buf_b + vt.cap);                    // [nb + 1]
-  const int64_t room = ((int64_t)2 * vt.cap * 64 - (int64_t)16 * vt.cap) / 12 - 2;  // three int32 arrays of nb + 1 entries each
-  if (cols < 1 || rows < 1 || nb64 > room || nb64 > (1 << 24)) {
+  int32_t *bstart = vt.bgrid + (int64_t)p * 3 * (vt.nb_max + 1);  // [nb + 1]
+  if (cols < 1 || rows < 1 || nb64 > vt.nb_max) {
     if (lane == 0) { m.status = VH_VOTE_UNSUPPORTED; if (out_count) out_count[p] = 0; }
     return;
   }

@@ -36,6 +36,8 @@ struct VhVote {
   vh_sh::Node *node;       // [P][cap]
   vh_sh::Half *half;       // [P][8 cap] half-edge records, four slots per triangle; before the sweep the sort's ping-pong buffers, after the tally the bucketing's scratch
   VhVoteMeta *meta;        // [P]
+  int32_t *bgrid;          // [P][3][nb_max + 1] bucketFeatures: per bucket first position / shuffle offset / output offset
+  int32_t nb_max;          // buckets the grid of a list may have
 };
 
 // the lists of S streams (one step) enter the batch as its lists [p0, p0 + S); vote = 0: no vote (stereo lists)
@@ -68,18 +70,21 @@ struct VhVoteBuffers {
   uint32_t *lfsr = nullptr;   // the shuffle's random sequence from seed 5 (matcher.cpp:130,160), lfsr_n draws
   int32_t lfsr_n = 0;
 
-  hipError_t alloc(int32_t P, int32_t cap, int32_t out_cap_) {
+  // nb_max: bound on the bucket grid of Matcher::bucketFeatures (columns x rows) for these lists
+  hipError_t alloc(int32_t P, int32_t cap, int32_t out_cap_, int32_t nb_max) {
     release();
+    if (nb_max < 1) nb_max = 1;
     if (P < 1) P = 1;
     if (cap < 4) cap = 4;
     if (out_cap_ < 1) out_cap_ = 1;
     const int32_t hs = vh_sh::hash_size(cap);
     const auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t n = (size_t)P * (size_t)cap;
-    const size_t sz[12] = {n * 48, n * 8, n * 8, n * 4, n * 4, n * sizeof(vh_sh::Node), 8 * n * sizeof(vh_sh::Half),
-                           (size_t)P * sizeof(VhVoteMeta), (size_t)P * (size_t)out_cap_ * 48, (size_t)P * 4, (size_t)cap * 4, n * 8};
-    size_t off[12], total = 0;
-    for (int k = 0; k < 12; k++) { off[k] = total; total += up(sz[k]); }
+    const size_t sz[13] = {n * 48, n * 8, n * 8, n * 4, n * 4, n * sizeof(vh_sh::Node), 8 * n * sizeof(vh_sh::Half),
+                           (size_t)P * sizeof(VhVoteMeta), (size_t)P * (size_t)out_cap_ * 48, (size_t)P * 4, (size_t)cap * 4, n * 8,
+                           (size_t)P * 3 * ((size_t)nb_max + 1) * 4};
+    size_t off[13], total = 0;
+    for (int k = 0; k < 13; k++) { off[k] = total; total += up(sz[k]); }
     const hipError_t e = hipMalloc((void **)&block, total);
     if (e != hipSuccess) { block = nullptr; return e; }
     bytes = total;
@@ -91,6 +96,7 @@ struct VhVoteBuffers {
     out = (vh_p_match *)(block + off[8]); out_count = (int32_t *)(block + off[9]); out_cap = out_cap_;
     lfsr = (uint32_t *)(block + off[10]); lfsr_n = cap;
     v.spts = (float2 *)(block + off[11]);
+    v.bgrid = (int32_t *)(block + off[12]); v.nb_max = nb_max;
     return hipSuccess;
   }
   // the table of draws; the copy is synchronous (pageable source)

@@ -68,8 +68,21 @@ def main():
         lanes = int(rng.choice([1, 2, 5, 16, 64]))
         mf, bw, bh = int(rng.integers(1, 5)), float(rng.choice([50, 33, 64, 100])), float(rng.choice([50, 40, 25]))
         want = [o.remove_outliers(pm)[0] for pm in lists]
-        got, _, _ = pkg.remove_outliers_device(lists, lanes_per_wave=lanes)
-        got_b, _, _ = pkg.remove_outliers_device(lists, lanes_per_wave=lanes, max_features=mf, bucket_width=bw, bucket_height=bh)
+        try:
+            got, _, _ = pkg.remove_outliers_device(lists, lanes_per_wave=lanes)
+            got_b, _, _ = pkg.remove_outliers_device(lists, lanes_per_wave=lanes, max_features=mf, bucket_width=bw, bucket_height=bh)
+        except pkg.VisoHipError as ex:  # which list, which call?
+            print(f"  REFUSED: batch {batches}: {ex}", flush=True)
+            for k, pm in enumerate(lists):
+                for mode in (0, mf):
+                    try:
+                        pkg.remove_outliers_device([pm], lanes_per_wave=lanes, max_features=mode, bucket_width=bw, bucket_height=bh)
+                    except pkg.VisoHipError as ex1:
+                        depth = o.remove_outliers(pm)[1]
+                        print(f"    list {k} alone (n {len(pm)}, max_features {mode}, oracle flip-stack depth {depth}): {ex1}", flush=True)
+                        np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_vote_fail_{batches}_{k}.npy"), pm)
+            bad += 1; batches += 1
+            continue
         nb = 0
         for k in range(P):
             if got[k].tobytes() != want[k].tobytes() or got_b[k].tobytes() != o.bucket_features(want[k], mf, bw, bh).tobytes():
