@@ -277,12 +277,15 @@ struct Group {
   }
 
   // Geometry of the bin-ordered emission (VhOrder): which v-bins and pixel rows each chunk of VH_CHUNK NMS blocks can
-  // touch, and -- the other way round -- which chunks can hold members of a v-bin / a pixel row.  Enabled when a
-  // chunk's counters fit the kernels' LDS tables; VH_ORDER=0 keeps the staging + bin_sort path (A/B runs, tests).
+  // touch, and -- the other way round -- which chunks can hold members of a v-bin / a pixel row.  Possible when a
+  // chunk's counters fit the kernels' LDS tables; VH_ORDER=1 selects it (the suite runs on both paths).
   int32_t setup_order() {
     order = VhOrder{};
-    static const bool off = [] { const char *e = getenv("VH_ORDER"); return e && e[0] == '0'; }();
-    if (off || g.nblocks <= 0 || sets.ubn < 1 || sets.vbn < 1) return VH_OK;
+    // Default OFF, on measurement (profiles/EXPERIMENTS.md, round 4): bit-exact and 6 % less exclusive kernel time in the
+    // detection chain (no bin_sort, no staging, no per-feature atomic), but its two extra latency-bound launches
+    // (count_chunks, a heavier scan) make the overlapped step 1 % SLOWER at KITTI size (99.7-100.9 k vs 100.5-101.8 k pairs/s).
+    static const bool on = [] { const char *e = getenv("VH_ORDER"); return e && e[0] == '1'; }();
+    if (!on || g.nblocks <= 0 || sets.ubn < 1 || sets.vbn < 1) return VH_OK;
     const int32_t n1 = g.n + 1, nch = g.nchunks, H = dims[1];
     std::vector<int32_t> vbf(nch), vf(nch), vbl(nch), vl(nch);
     int32_t VB = 1, VROW = 1;
