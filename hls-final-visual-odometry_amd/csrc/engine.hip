@@ -242,6 +242,16 @@ struct Group {
     return VH_OK;
   }
 
+  // release one block of `allocs` early (the work that used it must have completed)
+  void dfree(void *q) {
+    if (!q) return;
+    auto it = std::find(allocs.begin(), allocs.end(), q);
+    if (it == allocs.end()) return;
+    (void)hipStreamSynchronize(down_stream);
+    (void)hipFree(q);
+    allocs.erase(it);
+  }
+
   // ---- geometry ----------------------------------------------------------
   static int32_t block_count(int32_t extent, int32_t n) {
     // for (i=n+margin; i<extent-n-margin; i+=n+1)   (matcher.cpp:381-382)
@@ -1001,6 +1011,8 @@ struct Group {
     for (int32_t s = 0; s < S; s++)
       if (sl.h_cnt[s] > sl.width || sl.h_cnt[S + s]) return VH_ERR_CAPACITY;  // a list longer than what was downloaded / a truncated feature set
     if (bcap < need) {
+      for (void *old : {(void *)d_bucket, (void *)d_post_xyz}) dfree(old);  // (the superseded blocks: a caller raising max_features step by step must not pile them up)
+      d_bucket = nullptr; d_post_xyz = nullptr;
       if (h_bucket) { VH_HIP(hipHostFree(h_bucket)); h_bucket = nullptr; }
       VH_HIP(hipHostMalloc((void **)&h_bucket, sizeof(vh_p_match) * (size_t)S * need, hipHostMallocDefault));
       if (!h_bcnt) VH_HIP(hipHostMalloc((void **)&h_bcnt, sizeof(int32_t) * (size_t)S, hipHostMallocDefault));
@@ -1172,6 +1184,7 @@ struct Group {
     if (cap_ps < 1 || (e && mono)) return VH_ERR_INVALID_ARG;
     if (e && (!rand3 || e->ransac_iters < 1)) return VH_ERR_INVALID_ARG;
     if (mono && (!rand8 || mono->ransac_iters < 1 || (int64_t)S * vote_steps * mono->ransac_iters > (int64_t)1 << 31)) return VH_ERR_INVALID_ARG;
+    if (mono && (int64_t)S * vote_steps > 65535) return VH_ERR_UNSUPPORTED;  // (the monocular kernels put the list on grid.y: fewer steps per batch)
     if (!allocated || last_method < 0) return VH_ERR_STATE;
     if (e && last_method != VH_METHOD_QUAD) return VH_ERR_STATE;        // the stereo estimator needs both cameras of both frames
     if (mono && last_method == VH_METHOD_STEREO) return VH_ERR_STATE;   // the monocular one the left camera of both frames
@@ -1641,6 +1654,8 @@ int32_t vh_match_features(vh_matcher *m, int32_t method, const double *Tr_delta1
 int32_t vh_bucket_features(vh_matcher *m, int32_t max_features, float bucket_width, float bucket_height) {
   Group *gq = (Group *)m; ENTER(gq);
   if (max_features < 1 || !(bucket_width > 0) || !(bucket_height > 0)) return VH_ERR_INVALID_ARG;
+  // (a bucket grid beyond 2^24 cells -- bucket sides of a fraction of a pixel -- would overflow the reference's int arithmetic too)
+  if (gq->allocated && ((double)gq->dims[0] / bucket_width + 1) * ((double)gq->dims[1] / bucket_height + 1) > (double)(1 << 24)) return VH_ERR_INVALID_ARG;
   const int32_t rc = gq->fetch_matches(0);
   if (rc) return rc == VH_ERR_STATE ? VH_OK : rc;  // nothing matched yet: nothing to bucket
   bucket_host(gq->host_matches[0], max_features, bucket_width, bucket_height);
@@ -1842,6 +1857,7 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
   const int64_t total = offsets[n_sets], cap = std::max<int64_t>(nmax, 1);
   if (total > 0 && !pm) return VH_ERR_INVALID_ARG;
   if ((int64_t)n_sets * e->ransac_iters > (int64_t)1 << 31) return VH_ERR_UNSUPPORTED;
+  if (n_sets > 65535) return VH_ERR_UNSUPPORTED;  // (the hypothesis and triangulation kernels put the list on grid.y)
   const int32_t rc = select_device(device);
   if (rc) return rc;
   const size_t nr = (size_t)n_sets * e->ransac_iters * 8;
@@ -1862,7 +1878,8 @@ int32_t vh_estimate_motion_mono(const vh_mono_params *e, int32_t device, int32_t
   if (er == hipSuccess) {
     vh_launch_mono(*e, n_sets, (const vh_p_match *)d, 0, (const int32_t *)(d + o_off), nullptr, 0, (const int32_t *)(d + o_r), d + o_scr, cap,
                    (double *)(d + o_tr), (int32_t *)(d + o_ok), (int32_t *)(d + o_ok) + n_sets, (int32_t *)(d + o_inl), 0, nullptr);
-    er = hipDeviceSynchronize();
+    er = hipGetLastError();  // (a rejected launch is not reported by the synchronisation)
+    if (er == hipSuccess) er = hipDeviceSynchronize();
   }
   if (er == hipSuccess) er = hipMemcpy(tr, d + o_tr, b_tr, hipMemcpyDeviceToHost);
   if (er == hipSuccess) er = hipMemcpy(ok, d + o_ok, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost);

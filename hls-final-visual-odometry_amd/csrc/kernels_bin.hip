@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
       // (ranks within a row are 0 .. count-1, each taken once: emit_features' LDS ranks + reserved offsets, or the cursor)
       int32_t rp = rs[row] + (staged ? rowrel : atomicAdd(&rcur[row], 1));
       VH_CHECK_RANGE(s, 4, rp, rs[row], rs[row + 1]);
-      rpos[rp] = p;
+      if (rp < rs[nrow]) rpos[rp] = p;  // (one compare per feature: a rank beyond the row index -- an invariant broken upstream -- must not become a stray write)
     }
   }
 }

@@ -40,7 +40,8 @@ namespace {
 
 #define MONO_T 256
 #ifndef MONO_LDS_ROWS
-#define MONO_LDS_ROWS 640  // 45 KB: inlier sets of bucketed lists (a few hundred) fit; longer ones take the global-memory path
+#define MONO_LDS_ROWS 640  // inlier sets of bucketed lists (a few hundred) fit; longer ones take the global-memory path.  mono_final_a holds
+                           // the refit system (46 KB) AND the cooperative SVD's term scratch (41 KB) in LDS: 88 KB per workgroup -- gfx950's 160 KB only
 #endif
 
 __device__ __forceinline__ double sign_of(double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); }
@@ -750,6 +751,7 @@ mono_final_a_kernel(vh_mono_params e, const vh_p_match *__restrict__ pm_base, in
   // out an L2 round trip (7.8 of the 15 ms a 256 x 400 x 2000 batch took), from LDS a few dozen cycles.
   __shared__ double sA[MONO_LDS_ROWS * 9];
   __shared__ double sT[MONO_LDS_ROWS * 8];        // the cooperative SVD's term scratch
+  static_assert(sizeof(double) * MONO_LDS_ROWS * 17 <= 150 * 1024, "mono_final_a: refit system + term scratch must fit gfx950's 160 KB of LDS (lower MONO_LDS_ROWS for a smaller part)");
   __shared__ int32_t sNeg[9], sWave[MONO_T / 64], sBase;
   const int32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const MonoList L = mono_list(s, pm_base, pm_stride, offsets, counts, count_cap, scratch, cap);
