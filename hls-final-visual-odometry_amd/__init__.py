@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "vh_match_features", "vh_remove_outliers", "vh_remove_outliers_pm", "vh_remove_outliers_device", "vh_bucket_features", "vh_get_matches", "vh_get_features", "vh_synchronize",
     "vh_set_stream", "vh_clear_stream", "vh_stream_wait_images", "vh_host_alloc", "vh_host_free", "vh_compute_features", "vh_filters", "vh_create_index", "vh_match_all", "vh_match_all_prior", "vh_match",
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
-    "vh_group_push_back", "vh_group_match_features", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
+    "vh_group_push_back", "vh_group_match_features", "vh_group_match_features_prior", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_clear_stream", "vh_group_stream_wait_images", "vh_group_profile_enable",
     "vh_group_profile_read", "vh_group_profile_reset", "vh_group_debug_fail_next_alloc",
     "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion", "vh_group_search_stats",
@@ -160,7 +160,7 @@ def _lib():
             "vh_group_create": [vp, i32, i32, i32, i32, vp], "vh_group_destroy": [vp], "vh_group_streams": [vp],
             "vh_group_push_back_device": [vp, vp, vp, i64, vp, i32],
             "vh_group_push_back": [vp, vp, vp, i64, vp, i32],
-            "vh_group_match_features": [vp, i32], "vh_group_get_matches": [vp, i32, vp, i32, vp],
+            "vh_group_match_features": [vp, i32], "vh_group_match_features_prior": [vp, i32, vp], "vh_group_get_matches": [vp, i32, vp, i32, vp],
             "vh_group_get_matches_all": [vp, vp, i32, vp],
             "vh_group_download_matches_async": [vp, vp, i32, vp], "vh_group_wait_download": [vp],
             "vh_group_get_features": [vp, i32, i32, vp, i32, vp], "vh_group_get_counts": [vp, vp, vp],
@@ -378,6 +378,11 @@ class StreamGroup:
     def removeOutliers(self, host_threads: int = 0):
         """Matcher.removeOutliers for every stream, on `host_threads` host workers (0: all)."""
         _check(_lib().vh_group_remove_outliers(self._h, int(host_threads)), "vh_group_remove_outliers")
+
+    def matchFeaturesPrior(self, method: int, Tr_delta):
+        """matchFeatures with a motion prior per stream: Tr_delta [S, 4, 4] (vh_group_match_features_prior)."""
+        tr = np.ascontiguousarray(Tr_delta, dtype=np.float64).reshape(self.S, 16)
+        _check(_lib().vh_group_match_features_prior(self._h, int(method), _ptr(tr)), "vh_group_match_features_prior")
 
     def getMatches(self, stream: int) -> np.ndarray:
         n = C.c_int32(0)

@@ -204,7 +204,7 @@ struct Group {
     device_bytes = 0;
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0; ev_down_valid = false;
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
-    d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr; order = VhOrder{};
+    d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr; order = VhOrder{}; d_prior_tr = nullptr;
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk2[0] = d_mchunk2[1] = nullptr; d_redo = nullptr;
     for (int k = 0; k < 2; k++) if (h_out[k]) { (void)hipHostFree(h_out[k]); h_out[k] = nullptr; d_out_mapped[k] = nullptr; }
     if (h_matches) { (void)hipHostFree(h_matches); h_matches = nullptr; d_matches_mapped = nullptr; }
@@ -649,23 +649,29 @@ struct Group {
     return VH_OK;
   }
 
-  int32_t match(int32_t method) {
+  // tr16: null, or [S][16] row-major motion estimates for the quad method's prior (kernels_prior.hip); the intrinsics must be set
+  double *d_prior_tr = nullptr;
+  int32_t match(int32_t method, const double *tr16 = nullptr) {
     if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
     if (!allocated || failed) return VH_ERR_STATE;
+    if (tr16 && method != VH_METHOD_QUAD) tr16 = nullptr;  // (stock libviso2 uses the prediction in the quad circle only)
+    if (tr16 && !(p.f > 0 && p.base > 0)) return VH_ERR_STATE;  // setIntrinsics first
     if (match_dirty) { const int32_t rr = match_recover(); if (rr) return rr; }
+    if (tr16 && !d_prior_tr) { const int32_t rt = dmalloc(&d_prior_tr, 16 * (size_t)S, false); if (rt) { d_prior_tr = nullptr; return rt; } }
     // everything that can fail without a kernel of the step in flight comes first
     bool fresh_mask = false;
     if (method == VH_METHOD_FLOW && !d_mask) {
       int32_t rc = dmalloc(&d_mask, (size_t)S * dims[0] * dims[1], false); if (rc) { d_mask = nullptr; return rc; }
       fresh_mask = true;
     }
-    const int32_t rc = match_queued(method, fresh_mask);
+    const int32_t rc = match_queued(method, fresh_mask, tr16);
     if (rc) match_dirty = true;
     return rc;
   }
 
-  int32_t match_queued(int32_t method, bool fresh_mask) {
-    const VhMatchArgs a = match_args(method);
+  int32_t match_queued(int32_t method, bool fresh_mask, const double *tr16) {
+    VhMatchArgs a = match_args(method);
+    a.prior = tr16 ? 1 : 0;
     hipStream_t ms = match_stream, ps = post_stream;
     const int32_t buf = (int32_t)(match_seq++ & 1);
     // the current slot's detection+indexing must be complete (the previous
@@ -677,6 +683,11 @@ struct Group {
     const bool spec = choose_loop();
     { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo + (size_t)buf * S, spec ? 1 : 0, ms); }
     VH_HIP(hipGetLastError());
+    if (tr16) {  // hop 2 of the circle, per driving feature, behind the 1p -> 2p table of the launch above
+      VH_HIP(hipMemcpyAsync(d_prior_tr, tr16, sizeof(double) * 16 * (size_t)S, hipMemcpyHostToDevice, ms));
+      { Scope sc(this, "quad_prior", ms); vh_launch_quad_prior(sets, a, d_prior_tr, p.f, p.cu, p.cv, p.base, d_best2[buf], ms); }
+      VH_HIP(hipGetLastError());
+    }
     VH_HIP(hipEventRecord(ev_tables[buf], ms));
     VH_HIP(hipStreamWaitEvent(ps, ev_tables[buf], 0));
     int32_t *d_mchunk = d_mchunk2[buf];  // zeroed by the previous launch's emission (at allocation for the first two)
@@ -1543,6 +1554,10 @@ int32_t vh_group_match_features(vh_group *g, int32_t method) {
   Group *gq = (Group *)g; ENTER(gq);
   return gq->match(method);
 }
+int32_t vh_group_match_features_prior(vh_group *g, int32_t method, const double *Tr_delta16) {
+  Group *gq = (Group *)g; ENTER(gq);
+  return gq->match(method, Tr_delta16);
+}
 int32_t vh_group_get_matches(vh_group *g, int32_t stream, vh_p_match *out, int32_t cap, int32_t *n) {
   Group *gq = (Group *)g; ENTER(gq);
   return gq->get_matches(stream, out, cap, n);
@@ -1647,9 +1662,8 @@ int32_t vh_push_back_device(vh_matcher *m, const void *dI1, const void *dI2, con
   return gq->push_device(dI1, dI2, 0, dims, replace);
 }
 int32_t vh_match_features(vh_matcher *m, int32_t method, const double *Tr_delta16) {
-  (void)Tr_delta16;  // accepted and ignored, as Matcher::matchFeatures does (matcher.cpp:93-111)
   Group *gq = (Group *)m; ENTER(gq);
-  return gq->match(method);
+  return gq->match(method, Tr_delta16);  // (null: as the reference's Matcher::matchFeatures, which ignores its Tr_delta, matcher.cpp:93-111)
 }
 int32_t vh_bucket_features(vh_matcher *m, int32_t max_features, float bucket_width, float bucket_height) {
   Group *gq = (Group *)m; ENTER(gq);

@@ -754,6 +754,7 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best, int32_t *__res
   __shared__ uint32_t sAux[4 * 64];  // per wave: their u | v << 16 (tested flow loop) or key seeds (stereo)
   __shared__ uint32_t sAux2[SPEC ? 1 : 4 * 64];  // per wave: u | v << 16 (tested stereo loop)
   const int32_t pass = blockIdx.y, stream = blockIdx.z;
+  if (a.prior && pass == 1) return;  // (searched per driving feature, with its prediction: kernels_prior.hip)
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
   uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
@@ -869,7 +870,7 @@ __global__ void chain_kernel(VhSets s, VhMatchArgs a, int32_t method, const int3
     } else {
       if (n2p > 0 && n1c > 0 && n2c > 0) {
         const int32_t i2p = T[0 * cap + i];
-        const int32_t i2c = T[1 * cap + i2p];
+        const int32_t i2c = T[1 * cap + (a.prior ? i : i2p)];
         const int32_t i1c = T[2 * cap + i2c];
         const int32_t i1p2 = T[3 * cap + i1c];
         c = make_int4((int32_t)uv1p[i], (int32_t)uv2p[i2p], (int32_t)uv1c[i1c], (int32_t)uv2c[i2c]);

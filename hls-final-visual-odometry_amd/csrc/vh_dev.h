@@ -159,6 +159,8 @@ struct VhMatchArgs {
   int32_t S;
   int32_t radius, disp_tol;
   int32_t wide_keys;  // test hook (VH_FLOW_WIDE_KEYS): 1 = never the 16-bit position keys, 2 = always the 64-bit keys
+  int32_t prior;      // quad with a motion prior (kernels_prior.hip): pass 1 is not searched by match_kernel, and its table is
+                      // indexed by the driving feature i1p instead of by the query i2p
 };
 
 __host__ __device__ inline int32_t vh_set_id(int32_t S, int32_t pair, int32_t stream, int32_t cam) {
@@ -212,6 +214,8 @@ void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, i
 void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, double v_, int32_t *best,
                            hipStream_t st);
 void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, hipStream_t st);
+void vh_launch_quad_prior(const VhSets &s, const VhMatchArgs &a, const double *tr, double f, double cu, double cv, double base, int32_t *best,
+                          hipStream_t st);
 // chain: [stream][cap][2] int4 = {i1p,i2p,i1c,i2c} (z = -2: no match), {uv1p,uv2p,uv1c,uv2c}
 void vh_launch_chain(const VhSets &s, const VhMatchArgs &a, int32_t method, const int32_t *best,
                      int4 *chain, uint32_t *mask, uint32_t epoch, int32_t *mchunk, hipStream_t st);

@@ -137,8 +137,15 @@ int32_t vh_host_free(void *ptr);
 
 /* Matcher::matchFeatures(method, Tr_delta) (src/matcher.h:128,
  * src/matcher.cpp:93-111) with the stock Matcher::matching behind it
- * (src/matcher.cpp:274-344).  Tr_delta16 (row-major 4x4) is accepted and
- * ignored, as the reference does.  The reference's matchFeatures goes on to
+ * (src/matcher.cpp:274-344).  Tr_delta16 = NULL: no motion prior -- what the
+ * reference's matchFeatures does with ANY Tr_delta (it ignores the argument),
+ * and what the C++ shim passes.  Tr_delta16 != NULL (row-major 4x4) with
+ * method 2 after vh_set_intrinsics: stock libviso2's prior
+ * [upstream-recollection; absent from the reference tree] -- the hop previous
+ * right -> current right of the quad circle is searched with findMatch's
+ * prediction term (src/matcher.cpp:257-262, pinned) around the position that
+ * Tr_delta predicts for the 3-d point of the (1p, 2p) pair
+ * (csrc/kernels_prior.hip).  VH_ERR_STATE without intrinsics (f, base > 0).  The reference's matchFeatures goes on to
  * call removeOutliers (src/matcher.cpp:108); here that is the separate
  * vh_remove_outliers below, which the C++ shim calls for you. */
 int32_t vh_match_features(vh_matcher *m, int32_t method, const double *Tr_delta16);
@@ -260,6 +267,8 @@ int32_t vh_group_push_back_device(vh_group *g, const void *dI1, const void *dI2,
 int32_t vh_group_push_back(vh_group *g, const uint8_t *I1, const uint8_t *I2,
                            int64_t stride_bytes, const int32_t dims[3], int32_t replace);
 int32_t vh_group_match_features(vh_group *g, int32_t method);
+/* ... with a motion prior per stream, Tr_delta16[S][16] (see vh_match_features); NULL: none */
+int32_t vh_group_match_features_prior(vh_group *g, int32_t method, const double *Tr_delta16);
 /* vh_remove_outliers for every stream of the group, `host_threads` workers
  * (<= 0: one per hardware thread).  Host-bound: a few ms per stream. */
 int32_t vh_group_remove_outliers(vh_group *g, int32_t host_threads);

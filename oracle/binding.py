@@ -210,6 +210,19 @@ class Oracle:
             raise ValueError("vo_matching: invalid method")
         return out[:min(n.value, cap)].copy()
 
+    def matching_quad_prior(self, params, dims, tr16, m1p, m2p, m1c, m2c):
+        """Quad matching with the motion prior Tr_delta (row-major 4x4) on hop 2 [upstream-recollection]."""
+        sets = [_feat(m) for m in (m1p, m2p, m1c, m2c)]
+        cap = max(s[1] for s in sets) + 1
+        tr = np.ascontiguousarray(tr16, np.float64).reshape(16)
+        out = np.zeros(cap, P_MATCH_DTYPE); n = C.c_int32(0)
+        rc = self.lib.vo_matching_quad_prior(C.byref(params), _dims(dims), _ptr(tr),
+                                             _ptr(sets[0][0]), C.c_int32(sets[0][1]), _ptr(sets[1][0]), C.c_int32(sets[1][1]),
+                                             _ptr(sets[2][0]), C.c_int32(sets[2][1]), _ptr(sets[3][0]), C.c_int32(sets[3][1]),
+                                             _ptr(out), C.c_int32(cap), C.byref(n))
+        assert rc == 0
+        return out[:min(n.value, cap)].copy()
+
     def bucket_features(self, pm, max_features, bw, bh):
         pm = np.ascontiguousarray(pm, dtype=P_MATCH_DTYPE).copy()
         n = self.lib.vo_bucket_features(_ptr(pm), C.c_int32(len(pm)), C.c_int32(max_features),

@@ -450,6 +450,57 @@ int32_t vo_matching(const vo_params *p, const int32_t dims[3], int32_t method,
   return 0;
 }
 
+/* Quad matching with the motion prior of stock libviso2's Matcher::matching [upstream-recollection: the code is
+ * absent from the reference tree, whose matchFeatures accepts Tr_delta and ignores it, src/matcher.cpp:93-111; the
+ * only part the reference pins is findMatch's u_,v_ cost term, src/matcher.cpp:257-262].  Hop 2 of the circle,
+ * previous right -> current right, is searched around the position predicted for the current right image: the 3-d
+ * point of the (1p, 2p) pair, moved by Tr_delta (row-major 4x4), projected with the intrinsics of `p`. */
+int32_t vo_matching_quad_prior(const vo_params *p, const int32_t dims[3], const double *tr,
+                               const int32_t *m1p, int32_t n1p, const int32_t *m2p, int32_t n2p,
+                               const int32_t *m1c, int32_t n1c, const int32_t *m2c, int32_t n2c,
+                               vo_p_match *out, int32_t cap, int32_t *n_out) {
+  const int32_t ubn = (int32_t)ceilf((float)dims[0] / (float)p->match_binsize);
+  const int32_t vbn = (int32_t)ceilf((float)dims[1] / (float)p->match_binsize);
+  int32_t cnt = 0;
+  *n_out = 0;
+  if (n1p <= 0 || n2p <= 0 || n1c <= 0 || n2c <= 0) return 0;
+  vo_index k1p = vo_index_make(p, m1p, n1p, ubn, vbn);
+  vo_index k2p = vo_index_make(p, m2p, n2p, ubn, vbn);
+  vo_index k1c = vo_index_make(p, m1c, n1c, ubn, vbn);
+  vo_index k2c = vo_index_make(p, m2c, n2c, ubn, vbn);
+  for (int32_t i1p = 0; i1p < n1p; i1p++) {
+    const int32_t i2p = vo_find_match(p, m1p, i1p, m2p, k2p.bin_start, k2p.list, ubn, vbn, 0, -1, -1);
+    const int32_t u1p = m1p[12 * (int64_t)i1p], v1p = m1p[12 * (int64_t)i1p + 1];
+    const int32_t u2p = m2p[12 * (int64_t)i2p], v2p = m2p[12 * (int64_t)i2p + 1];
+    double d = (double)u1p - (double)u2p;
+    if (d < 1.0) d = 1.0;
+    const double x1p = ((double)u1p - p->cu) * p->base / d;
+    const double y1p = ((double)v1p - p->cv) * p->base / d;
+    const double z1p = p->f * p->base / d;
+    const double x2c = tr[0] * x1p + tr[1] * y1p + tr[2] * z1p + tr[3] - p->base;
+    const double y2c = tr[4] * x1p + tr[5] * y1p + tr[6] * z1p + tr[7];
+    const double z2c = tr[8] * x1p + tr[9] * y1p + tr[10] * z1p + tr[11];
+    const double u2c_ = p->f * x2c / z2c + p->cu;
+    const double v2c_ = p->f * y2c / z2c + p->cv;
+    const int32_t i2c = vo_find_match(p, m2p, i2p, m2c, k2c.bin_start, k2c.list, ubn, vbn, 1, u2c_, v2c_);
+    const int32_t i1c = vo_find_match(p, m2c, i2c, m1c, k1c.bin_start, k1c.list, ubn, vbn, 0, -1, -1);
+    const int32_t i1p2 = vo_find_match(p, m1c, i1c, m1p, k1p.bin_start, k1p.list, ubn, vbn, 1, -1, -1);
+    if (i1p2 == i1p) {
+      const int32_t u1c = m1c[12 * (int64_t)i1c], v1c = m1c[12 * (int64_t)i1c + 1];
+      const int32_t u2c = m2c[12 * (int64_t)i2c], v2c = m2c[12 * (int64_t)i2c + 1];
+      if (u1p >= u2p && u1c >= u2c)
+        vo_emit(out, cap, &cnt, (float)u1p, (float)v1p, i1p, (float)u2p, (float)v2p, i2p,
+                (float)u1c, (float)v1c, i1c, (float)u2c, (float)v2c, i2c);
+    }
+  }
+  vo_index_free(&k1p);
+  vo_index_free(&k2p);
+  vo_index_free(&k1c);
+  vo_index_free(&k2c);
+  *n_out = cnt;
+  return 0;
+}
+
 void vo_match_all(const vo_params *p, const int32_t dims[3], const int32_t *m1, int32_t n1,
                   const int32_t *m2, int32_t n2, int32_t flow, int32_t *best) {
   const int32_t ubn = (int32_t)ceilf((float)dims[0] / (float)p->match_binsize);

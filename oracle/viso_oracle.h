@@ -117,6 +117,11 @@ int32_t vo_matching(const vo_params *p, const int32_t dims[3], int32_t method,
                     const int32_t *m1c, int32_t n1c,
                     const int32_t *m2c, int32_t n2c,
                     vo_p_match *out, int32_t cap, int32_t *n_out);
+/* quad matching with stock libviso2's motion prior on the hop previous right -> current right [upstream-recollection] */
+int32_t vo_matching_quad_prior(const vo_params *p, const int32_t dims[3], const double *tr16,
+                               const int32_t *m1p, int32_t n1p, const int32_t *m2p, int32_t n2p,
+                               const int32_t *m1c, int32_t n1c, const int32_t *m2c, int32_t n2c,
+                               vo_p_match *out, int32_t cap, int32_t *n_out);
 
 /* For all i1 in set 1: best match index in set 2 (vo_find_match for every
  * query).  Used to check the GPU's whole-set match tables. */

@@ -606,6 +606,53 @@ def test_index_invariants_on_the_checking_build(pkg, gpu):
 
 
 @pytest.mark.gpu
+def test_quad_matching_with_motion_prior(pkg, ob, oracle, gpu):
+    """vh_match_features with a Tr_delta.  The reference tree ignores the argument; the part it pins is
+    findMatch's prediction term (test_find_match_prior_term).  The composition -- stock libviso2 predicts the position
+    in the current right image from the (1p, 2p) pair and Tr_delta and searches hop 2 of the quad circle around it --
+    is [upstream-recollection], restated in oracle/viso_oracle.c: vo_matching_quad_prior; the GPU is bit-exact against
+    that, for a single matcher and for a group with a different motion per stream.  Without a Tr_delta nothing changes."""
+    W, H, S = 480, 200, 2
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    K = dict(f=400.0, cu=W / 2.0, cv=H / 2.0, base=0.5)
+    seqs = [pkg.synth.stereo_sequence(W, H, 2, disparity=7 + s, blur=4, seed=500 + s) for s in range(S)]
+    po = ob.Params.default(**K)
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(2)] for s in range(S)]
+
+    def motion(tz, ry, tx):
+        T = np.eye(4)
+        T[0, 0] = np.cos(ry); T[0, 2] = np.sin(ry); T[2, 0] = -np.sin(ry); T[2, 2] = np.cos(ry)
+        T[0, 3] = tx; T[2, 3] = tz
+        return T
+    trs = [motion(-0.4, 0.01, 0.05), motion(1.5, -0.08, -0.6)]  # a plausible step forward; a prediction far off the truth
+    plain = [oracle.matching(po, dims, 2, F[s][0][0], F[s][0][1], F[s][1][0], F[s][1][1]) for s in range(S)]
+    want = [[oracle.matching_quad_prior(po, dims, tr, F[s][0][0], F[s][0][1], F[s][1][0], F[s][1][1]) for tr in trs] for s in range(S)]
+    assert any(want[s][k].tobytes() != plain[s].tobytes() for s in range(S) for k in range(2))  # the prior changes something
+    assert all(len(want[s][k]) > 50 for s in range(S) for k in range(2))
+    m = pkg.Matcher(pkg.Params.default(), outlier_removal=False)
+    for t in range(2):
+        m.pushBack(seqs[0][t][0], seqs[0][t][1], dims, False)
+    with pytest.raises(pkg.VisoHipError) as ex:
+        m.matchFeatures(pkg.METHOD_QUAD, Tr_delta=trs[0])  # no intrinsics yet
+    assert ex.value.code == pkg.VH_ERR_STATE
+    m.setIntrinsics(K["f"], K["cu"], K["cv"], K["base"])
+    for k in (0, 1, 0):
+        m.matchFeatures(pkg.METHOD_QUAD, Tr_delta=trs[k])
+        assert m.getMatches().tobytes() == want[0][k].tobytes(), k
+        m.matchFeatures(pkg.METHOD_QUAD)  # and without: the plain circle
+        assert m.getMatches().tobytes() == plain[0].tobytes()
+    m.matchFeatures(pkg.METHOD_FLOW, Tr_delta=trs[1])  # other methods take no prior
+    assert m.getMatches().tobytes() == oracle.matching(po, dims, 0, m1p=F[0][0][0], m1c=F[0][1][0]).tobytes()
+    m.close()
+    g = pkg.StreamGroup(S, pkg.Params.default(**K))
+    for t in range(2):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+    g.matchFeaturesPrior(pkg.METHOD_QUAD, np.stack([trs[1], trs[0]]))
+    assert g.getMatches(0).tobytes() == want[0][1].tobytes() and g.getMatches(1).tobytes() == want[1][0].tobytes()
+    g.close()
+
+
+@pytest.mark.gpu
 def test_bin_ordered_emission_path(pkg, gpu):
     """VH_ORDER=1: the detector's features go straight to their bin-order positions (count_chunks -> scan -> emission;
     csrc/vh_dev.h VhOrder) instead of through per-bin staging and bin_sort.  Same results, bit for bit: every other test of
