@@ -175,6 +175,51 @@ def test_gpu_group_estimate_motion_mono_on_device_matches(pkg, ob, oracle, gpu):
 
 
 @pytest.mark.gpu
+def test_gpu_device_post_stage_with_the_mono_estimator(pkg, ob, oracle, gpu):
+    """vh_group_post_begin_device / _finish_device with the monocular estimator as the last stage: the vote, the bucketing
+    and the pose of VisualOdometryMono::process (src/viso_mono.cpp:34-37) entirely on the GPU, two steps per batch, per
+    stream equal to the oracle's chain on the same flow matches; also without an estimator (lists only)."""
+    import ctypes as C
+    S, W, H, T = 3, 480, 200, 5
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, T, disparity=6 + s, blur=4, seed=410 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[oracle.compute_features(po, seqs[s][t][0], dims)[1] for t in range(T)] for s in range(S)]
+    e = ob.MonoParams.default(ransac_iters=300, height=1.65, f=400.0, cu=W / 2, cv=H / 2)
+    ge = _gpu_params(pkg, e)
+    raw = np.random.default_rng(4).integers(0, 2 ** 31 - 1, (T, S, 300, 8)).astype(np.int32)
+
+    def chain(t, s):
+        pm, _ = oracle.remove_outliers(oracle.matching(po, dims, 0, m1p=F[s][t - 1], m1c=F[s][t]))
+        q = pm.copy()
+        n = oracle.lib.vo_bucket_features(q.ctypes.data_as(C.c_void_p), len(q), 2, C.c_float(50), C.c_float(50))
+        return q[:n].copy()
+
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    g.postDeviceConfig(2, 2, 64)
+    for t in range(T):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), None, dims, False)
+        if t == 0:
+            continue
+        g.matchFeatures(pkg.METHOD_FLOW)
+        g.postBeginDevice(8192, 2, 50.0, 50.0, mono=ge, rand8=raw[t], want_lists=True)
+    for t in range(1, T):  # the oldest first; the last batch holds one step only and is launched by its finish call
+        got = g.postFinishDevice(T - 1 - t, want_lists=True)
+        for s in range(S):
+            q = chain(t, s)
+            ok_o, tr_o, inl_o = oracle.estimate_motion_mono(e, q, oracle.draw_samples_n(len(q), 8, 300, raw[t, s].reshape(-1)))
+            assert len(q) > 20 and got["lists"][s].tobytes() == q.tobytes(), (t, s)
+            assert got["ok"][s] == ok_o and got["n_inliers"][s] == len(inl_o) and _close(got["tr"][s], tr_o), (t, s)
+    # no estimator: the bucketed lists alone
+    g.postBeginDevice(8192, 3, 40.0, 30.0, want_lists=True)
+    got = g.postFinishDevice(0, want_lists=True, estimator=False)
+    for s in range(S):
+        pm, _ = oracle.remove_outliers(oracle.matching(po, dims, 0, m1p=F[s][T - 2], m1c=F[s][T - 1]))
+        assert got["lists"][s].tobytes() == oracle.bucket_features(pm, 3, 40, 30).tobytes()
+    g.close()
+
+
+@pytest.mark.gpu
 def test_gpu_pipelined_post_stage_with_the_mono_estimator(pkg, ob, oracle, gpu):
     """vh_group_post_begin / vh_group_post_finish_mono -- VisualOdometryMono::process after the matching
     (src/viso_mono.cpp:34-37) for a stream group: removeOutliers -> bucketFeatures(2, 50, 50) -> the monocular

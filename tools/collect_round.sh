@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): the tracked evidence of one round in one call.
 #   tools/collect_round.sh <tag>   ->  gpurun_out/{prof_<tag>, pmc_<tag>, <tag>_*.json/txt}
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$GRAFT_REPO_ROOT"
 tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1 || tail -5 gpurun_out/${TAG}_profile.log
 echo "profile_round done"
