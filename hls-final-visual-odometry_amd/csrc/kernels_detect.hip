@@ -938,27 +938,31 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
 // --------------------------------------------------------------- count_chunks
 // VhOrder: what every chunk of VH_CHUNK NMS blocks holds per (class, u-bin, v-bin) and per (class, v) row, from the
 // detector's position codes.  A chunk's counters are its own: LDS atomics, then plain stores -- no global atomic.
-__global__ void __launch_bounds__(256)
+// One WAVE per chunk (16 blocks per lane, all their records requested before the first is used): as a 256-thread
+// workgroup the kernel was three barrier-separated phases around one memory round trip, 8 workgroups per CU at a time.
+__global__ void __launch_bounds__(64)
 count_chunks_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec, VhSets s, VhOrder o) {
   extern __shared__ int32_t sCnt[];  // [nslot + 4 * VROW]
   const int32_t id = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int32_t nc = o.nslot + 4 * o.VROW;
-  for (int32_t k = tid; k < nc; k += 256) sCnt[k] = 0;
-  __syncthreads();
-  constexpr int BPL = VH_CHUNK / 256;
-  const int32_t n1 = g.n + 1;
-  const int32_t vbf = o.vb_first[chunk], vf = o.v_first[chunk];
+  constexpr int BPL = VH_CHUNK / 64;
   const uint2 *rp = reinterpret_cast<const uint2 *>(rec) + (int64_t)id * g.nblocks;
   const int32_t blk0 = chunk * VH_CHUNK + tid * BPL;
+  uint2 cw[BPL];
+#pragma unroll
+  for (int32_t k = 0; k < BPL; k++) cw[k] = rp[min(blk0 + k, g.nblocks - 1)];
+  const int32_t nc = o.nslot + 4 * o.VROW;
+  for (int32_t k = tid; k < nc; k += 64) sCnt[k] = 0;
+  __syncthreads();
+  const int32_t n1 = g.n + 1;
+  const int32_t vbf = o.vb_first[chunk], vf = o.v_first[chunk];
   int32_t by = blk0 / g.nbx, bx = blk0 - by * g.nbx;
 #pragma unroll
   for (int32_t k = 0; k < BPL; k++) {
     if (blk0 + k < g.nblocks) {
-      const uint2 cw = rp[blk0 + k];
       const int32_t u0 = bx * n1 + g.n + VH_MARGIN, v0 = by * n1 + g.n + VH_MARGIN;
 #pragma unroll
       for (int32_t q = 0; q < 4; q++) {
-        const uint32_t w = (q < 2) ? cw.x : cw.y;
+        const uint32_t w = (q < 2) ? cw[k].x : cw[k].y;
         const uint32_t pc = (q & 1) ? (w >> 16) : (w & 0xFFFFu);
         if (pc == VH_NO_CODE) continue;
         const int32_t uu = (u0 + (int32_t)(pc & 63u)) * g.scale, vv = (v0 + (int32_t)(pc >> 6)) * g.scale;
@@ -973,8 +977,8 @@ count_chunks_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec, VhS
   __syncthreads();
   int32_t *__restrict__ cb = o.cbin + ((int64_t)id * g.nchunks + chunk) * o.nslot;
   int32_t *__restrict__ cr = o.crow + ((int64_t)id * g.nchunks + chunk) * 4 * o.VROW;
-  for (int32_t k = tid; k < o.nslot; k += 256) cb[k] = sCnt[k];
-  for (int32_t k = tid; k < 4 * o.VROW; k += 256) cr[k] = sCnt[o.nslot + k];
+  for (int32_t k = tid; k < o.nslot; k += 64) cb[k] = sCnt[k];
+  for (int32_t k = tid; k < 4 * o.VROW; k += 64) cr[k] = sCnt[o.nslot + k];
 }
 
 // --------------------------------------------------------------------- planes
@@ -1058,7 +1062,7 @@ void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t
 void vh_launch_count_chunks(const VhImages &im, const VhGeom &g, const uint64_t *rec, const VhSets &s, const VhOrder &o, hipStream_t st) {
   if (g.nblocks <= 0 || !o.enabled) return;
   dim3 grid(g.nchunks, im.S * im.ncam);
-  hipLaunchKernelGGL(count_chunks_kernel, grid, dim3(256), sizeof(int32_t) * (size_t)(o.nslot + 4 * o.VROW), st, im, g, rec, s, o);
+  hipLaunchKernelGGL(count_chunks_kernel, grid, dim3(64), sizeof(int32_t) * (size_t)(o.nslot + 4 * o.VROW), st, im, g, rec, s, o);
 }
 
 void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
