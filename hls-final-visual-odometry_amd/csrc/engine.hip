@@ -517,7 +517,9 @@ struct Group {
     const int32_t ncam = dI2 ? 2 : 1;
     static const int subbatch_env = [] { const char *ev = getenv("VH_SUBBATCH"); return ev ? atoi(ev) : 0; }();
     const int64_t det_wgs = (int64_t)S * ncam * ((g.nblocks + 255) / 256);
-    const int32_t subbatch = subbatch_env > 0 ? subbatch_env : (serial ? 1 : (int32_t)std::min<int64_t>(4, det_wgs / 12000));
+    // (a mono push is half the detection work of a stereo one: 4 sub-batches of 64 KITTI images leave emit_features with two
+    //  rounds of workgroups per launch -- mono flow, S = 256: 1 / 2 / 4 / 8 sub-batches = 118 / 115 / 109 / 101 k frames/s)
+    const int32_t subbatch = subbatch_env > 0 ? subbatch_env : (serial ? 1 : (int32_t)std::min<int64_t>(4, det_wgs / (ncam == 2 ? 12000 : 40000)));
     const int32_t nsub = std::max(1, std::min(subbatch, S));
     const int32_t ssub = (S + nsub - 1) / nsub;
     for (int32_t s0 = 0; s0 < S; s0 += ssub) {
@@ -1226,12 +1228,16 @@ struct Group {
     };
     if (b->steps > 0 && (b->launched || b->steps >= vote_steps || !same(*b))) {  // the batch is closed (full, flushed, or configured differently): next one
       if ((rc = vote_launch(*b, vote_cur))) return rc;
-      vote_cur = (vote_cur + 1) % vote_batches;
+      const int32_t next = (vote_cur + 1) % vote_batches;
+      // the ring has come round: the next batch's results must have been handed out (checked before anything moves, so
+      // that the caller can finish those steps and begin this one again)
+      if (vbatch[(size_t)next].launched && vbatch[(size_t)next].busy && vbatch[(size_t)next].handed < vbatch[(size_t)next].steps) return VH_ERR_STATE;
+      vote_cur = next;
       b = &vbatch[(size_t)vote_cur];
     }
     if (b->steps == 0 || b->launched) {  // start the batch
-      if (b->launched) {  // the ring has come round: its results must have been handed out, its kernels are done
-        if (b->busy && b->handed < b->steps) return VH_ERR_STATE;  // results of `vote_steps * vote_batches` steps ago were never fetched
+      if (b->launched) {  // a batch of the previous round: its kernels must be done
+        if (b->busy && b->handed < b->steps) return VH_ERR_STATE;
         VH_HIP(hipEventSynchronize(b->ev_done));
       }
       b->steps = 0; b->launched = false; b->busy = false; b->handed = 0;

@@ -439,3 +439,49 @@ def test_gpu_device_post_stage_matches_the_oracle_chain(steps_per_batch, batches
         g.postFinishDevice(0)
     assert ex.value.code == pkg.VH_ERR_CAPACITY
     g.close()
+
+
+@pytest.mark.gpu
+def test_device_post_stage_ring_discipline(pkg, ob, oracle, gpu):
+    """Every step begun must be finished before the ring of steps_per_batch * batches steps comes round: the begin call
+    that would overwrite unfetched results is refused (VH_ERR_STATE) and changes nothing -- after the overdue finish it
+    goes through, and the results of all steps are still the oracle's."""
+    S, W, H = 2, 320, 160
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, 5, disparity=5 + s, blur=4, seed=600 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(5)] for s in range(S)]
+
+    def want(t, s):
+        pm, _ = oracle.remove_outliers(oracle.matching(po, dims, 2, F[s][t - 1][0], F[s][t - 1][1], F[s][t][0], F[s][t][1]))
+        return oracle.bucket_features(pm, 2, 50, 50)
+
+    g = pkg.StreamGroup(S, pkg.Params.default())
+    g.postDeviceConfig(1, 2, 3)
+    with pytest.raises(pkg.VisoHipError):
+        g.postDeviceConfig(0, 2, 1)
+
+    def step(t):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+        if t:
+            g.matchFeatures(pkg.METHOD_QUAD)
+    step(0); step(1)
+    g.postBeginDevice(4096, 2, 50.0, 50.0, want_lists=True)   # step 1 -> batch 0
+    step(2)
+    g.postBeginDevice(4096, 2, 50.0, 50.0, want_lists=True)   # step 2 -> batch 1
+    with pytest.raises(pkg.VisoHipError) as ex:
+        g.postDeviceConfig(2, 2, 1)  # steps in flight
+    assert ex.value.code == pkg.VH_ERR_STATE
+    step(3)
+    for attempt in range(2):  # refused twice in the same way: nothing moved
+        with pytest.raises(pkg.VisoHipError) as ex:
+            g.postBeginDevice(4096, 2, 50.0, 50.0, want_lists=True)  # would reuse batch 0: step 1 was never fetched
+        assert ex.value.code == pkg.VH_ERR_STATE
+    got1 = g.postFinishDevice(1, want_lists=True, estimator=False)  # step 1 (two begins ago)
+    g.postBeginDevice(4096, 2, 50.0, 50.0, want_lists=True)   # step 3 -> batch 0 again
+    got2 = g.postFinishDevice(1, want_lists=True, estimator=False)  # step 2
+    got3 = g.postFinishDevice(0, want_lists=True, estimator=False)  # step 3
+    for t, got in ((1, got1), (2, got2), (3, got3)):
+        for s in range(S):
+            assert got["lists"][s].tobytes() == want(t, s).tobytes(), (t, s)
+    g.close()
