@@ -1205,6 +1205,7 @@ struct Group {
     int32_t rc = bucket_need(max_features, bw, bh, &need, &grid);
     if (rc) return rc;
     cap_ps = std::min(cap_ps, mcap);
+    if (cap_ps > 65536) return VH_ERR_UNSUPPORTED;  // (the sweep's angular hash has VH_VOTE_HASH_MAX slots in LDS)
     if (vbatch.empty()) {
       vbatch.resize((size_t)vote_batches);
       vstep.assign((size_t)vote_steps * vote_batches, VoteStep{});
@@ -2074,6 +2075,7 @@ int32_t vh_remove_outliers_device(int32_t device, int32_t n_lists, const vh_p_ma
     cap = std::max(cap, counts[l]);
   }
   if (cap > 1 && !pm) return VH_ERR_INVALID_ARG;
+  if (cap > 65536) return VH_ERR_UNSUPPORTED;  // (the sweep's angular hash has VH_VOTE_HASH_MAX slots in LDS)
   const int32_t rc = select_device(device);
   if (rc) return rc;
   VhVoteBuffers vb;

@@ -422,6 +422,10 @@ void vh_launch_vote(const VhVote &vt, int32_t lanes, int32_t max_features, float
                     int32_t out_cap, int32_t *out_count, hipEvent_t *sweep_ev, hipStream_t st) {
   if (vt.P < 1) return;
   lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
+  {  // the lanes' hashes and flip stacks share 64 KB of LDS: fewer lists per wave for very long lists
+    const int32_t fit = (int32_t)(65536 / (sizeof(int32_t) * (size_t)(vt.hsize + VH_VOTE_PEND)));
+    if (lanes > fit) lanes = fit < 1 ? 1 : fit;
+  }
   hipLaunchKernelGGL(vote_order_kernel, dim3(vt.P), dim3(64), 0, st, vt);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[0], st);
   static const int32_t prio = [] { const char *e = getenv("VH_VOTE_PRIO"); return e ? atoi(e) : 3; }();
