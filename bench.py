@@ -469,6 +469,11 @@ def main():
 
         # -- device form (context measurements must never cost the line its headline: an error is reported in place of the number)
         B, NB, lanes = args.e2e_steps_per_batch, args.e2e_batches, args.e2e_lanes
+        # the ring of batches needs ~0.24 KB per match slot and list in flight: fewer steps per batch on a device with less free memory
+        free_b, _ = torch.cuda.mem_get_info()
+        per_step = S * cap_ps * 250.0
+        while B > 4 and B * NB * per_step > 0.7 * free_b:
+            B //= 2
         try:
             e2e = e2e_device(B, NB, lanes)
         except Exception as ex:  # e.g. not enough free HBM for the ring of batches

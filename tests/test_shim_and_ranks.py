@@ -83,7 +83,7 @@ def test_two_rank_launch_gloo(pkg):
     assert sorted(x["rank"] for x in r["ranks_seen"]) == [0, 1] and len({x["uuid"] for x in r["ranks_seen"]}) == 2
     # the agreed number of blocks (>= 3), each at least as long as the SLOWEST rank's 7 steps of 2 ms
     assert r["blocks"]["count"] >= 3 and all(b >= 7 * 0.002 for b in r["blocks"]["seconds_each"])
-    assert 2.0 <= r["ms_per_step"] < 10.0
+    assert 2.0 <= r["ms_per_step"] < 100.0  # (rank 1 sleeps 2 ms per step; the upper bound only guards against a clock that stopped meaning anything)
     assert r["value"] == pytest.approx(2 * 3 * 7 / (r["ms_per_step"] * 7e-3))  # whole-job aggregate over the MAX-reduced clock
 
 
