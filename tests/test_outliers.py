@@ -485,3 +485,30 @@ def test_device_post_stage_ring_discipline(pkg, ob, oracle, gpu):
         for s in range(S):
             assert got["lists"][s].tobytes() == want(t, s).tobytes(), (t, s)
     g.close()
+
+
+@pytest.mark.gpu
+def test_device_post_stage_leaves_stereo_lists_unvoted(pkg, ob, oracle, gpu):
+    """Stereo records carry no previous-frame position, so removeOutliers' flow vote does not apply to them (as in the
+    host form and the shim): the device post stage buckets them as they are; an estimator is refused for them."""
+    W, H = 320, 160
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    l, r = pkg.synth.stereo_sequence(W, H, 1, disparity=6, blur=4)[0]
+    po = ob.Params.default()
+    g = pkg.StreamGroup(1, pkg.Params.default())
+    g.postDeviceConfig(1, 2, 1)
+    g.pushBack(l[None], r[None], dims, False)
+    g.matchFeatures(pkg.METHOD_STEREO)
+    raw = g.getMatches(0)
+    assert len(raw) > 50
+    g.postBeginDevice(4096, 2, 50.0, 50.0, want_lists=True)
+    got = g.postFinishDevice(0, want_lists=True, estimator=False)
+    assert got["lists"][0].tobytes() == oracle.bucket_features(raw, 2, 50, 50).tobytes()
+    with pytest.raises(pkg.VisoHipError) as ex:
+        g.postBeginDevice(4096, 2, 50.0, 50.0, ego=pkg.EgoParams.default(f=400.0, cu=W / 2, cv=H / 2, base=0.5),
+                          rand3=np.zeros((1, 200, 3), np.int32))
+    assert ex.value.code == pkg.VH_ERR_STATE
+    with pytest.raises(pkg.VisoHipError) as ex:
+        g.postBeginDevice(4096, 2, 0.25, 50.0)  # a bucket below one pixel
+    assert ex.value.code == pkg.VH_ERR_INVALID_ARG
+    g.close()
