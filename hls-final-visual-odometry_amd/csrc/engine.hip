@@ -1152,7 +1152,7 @@ struct Group {
   }
 
   int32_t post_device_config(int32_t steps_per_batch, int32_t batches, int32_t lanes) {
-    if (steps_per_batch < 1 || steps_per_batch > 64 || batches < 1 || batches > 64 || lanes < 1 || lanes > 64) return VH_ERR_INVALID_ARG;
+    if (steps_per_batch < 1 || steps_per_batch > 256 || batches < 1 || batches > 64 || lanes < 1 || lanes > 64) return VH_ERR_INVALID_ARG;
     for (auto &b : vbatch) if (b.busy || b.steps) return VH_ERR_STATE;  // steps in flight
     vote_release();
     vote_steps = steps_per_batch; vote_batches = batches; vote_lanes = lanes;
@@ -1188,6 +1188,8 @@ struct Group {
     VH_HIP(hipMemcpyAsync(b.h_meta, b.vb.v.meta, sizeof(VhVoteMeta) * (size_t)v.P, hipMemcpyDeviceToHost, vs));
     if (b.want_lists) VH_HIP(hipMemcpyAsync(b.h_out, b.vb.out, sizeof(vh_p_match) * (size_t)v.P * b.vb.out_cap, hipMemcpyDeviceToHost, vs));
     VH_HIP(hipEventRecord(b.ev_done, vs));
+    static const bool serial_vote = [] { const char *ev = getenv("VH_VOTE_SERIAL"); return ev && ev[0] == '1'; }();
+    if (serial_vote) VH_HIP(hipStreamWaitEvent(stream, b.ev_done, 0));  // experiment: the matcher's next step waits for this batch
     b.launched = true;
     return VH_OK;
   }
@@ -1197,7 +1199,7 @@ struct Group {
     if (cap_ps < 1 || (e && mono)) return VH_ERR_INVALID_ARG;
     if (e && (!rand3 || e->ransac_iters < 1)) return VH_ERR_INVALID_ARG;
     if (mono && (!rand8 || mono->ransac_iters < 1 || (int64_t)S * vote_steps * mono->ransac_iters > (int64_t)1 << 31)) return VH_ERR_INVALID_ARG;
-    if (mono && (int64_t)S * vote_steps > 65535) return VH_ERR_UNSUPPORTED;  // (the monocular kernels put the list on grid.y: fewer steps per batch)
+    if ((int64_t)S * vote_steps > 65535) return VH_ERR_UNSUPPORTED;  // (the tally and the monocular kernels put the list on grid.y: fewer steps per batch)
     if (!allocated || last_method < 0) return VH_ERR_STATE;
     if (e && last_method != VH_METHOD_QUAD) return VH_ERR_STATE;        // the stereo estimator needs both cameras of both frames
     if (mono && last_method == VH_METHOD_STEREO) return VH_ERR_STATE;   // the monocular one the left camera of both frames
