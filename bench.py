@@ -305,7 +305,7 @@ def main():
     ap.add_argument("--no-e2e-host", action="store_true", help="skip the host-vote form of the as-shipped loop")
     ap.add_argument("--e2e-steps-per-batch", type=int, default=int(os.environ.get("VH_E2E_STEPS_PER_BATCH", "64")))
     ap.add_argument("--e2e-batches", type=int, default=int(os.environ.get("VH_E2E_BATCHES", "3")))
-    ap.add_argument("--e2e-lanes", type=int, default=int(os.environ.get("VH_E2E_LANES", "64")))
+    ap.add_argument("--e2e-lanes", type=int, default=int(os.environ.get("VH_E2E_LANES", "16")))
     ap.add_argument("--e2e-steps", type=int, default=0, help="steps of the device e2e loop (0: 4 x the steps in flight, at least 48)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",

@@ -1135,7 +1135,7 @@ struct Group {
   // 4x5 10.4, 8x5 11.7, 16x5 19.9, 32x3 25.3, 32x4 30.4, 48x3 30.2, 64x3 33.9; 1 list per wave, 4x5: 17.9.  A batch takes
   // 0.4-0.5 s from launch to results whatever its size (profiles/r04_vote_trace.txt): the rate is the number of steps in
   // flight over that latency, and a wave of 64 lists costs the chip 1/14 of what 64 single-list waves cost.
-  int32_t vote_steps = 64, vote_batches = 3, vote_lanes = 64;
+  int32_t vote_steps = 64, vote_batches = 3, vote_lanes = 16;
   int64_t post_dev_seq = 0;   // steps begun
   int32_t vote_cur = 0;       // batch receiving steps
   struct VoteStep { int32_t batch = -1, pos = 0; bool open = false; };

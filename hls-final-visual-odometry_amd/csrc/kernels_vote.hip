@@ -278,25 +278,54 @@ __global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes
 
 // ---- vote_tally --------------------------------------------------------------------------------------
 // remove_outliers.cpp:36-80: every triangle votes for each of its corners once per agreeing neighbour
-__global__ __launch_bounds__(256) void vote_tally_kernel(VhVote vt) {
-  const int32_t p = blockIdx.y;
-  const VhVoteMeta &m = vt.meta[p];
-  if (m.status != VH_VOTE_OK) return;
-  const int32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= m.ntri) return;
+__device__ __forceinline__ void tally_triangle(const VhVote &vt, int32_t p, int32_t t, int32_t &a, int32_t &b, int32_t &c, int32_t &va, int32_t &vb, int32_t &vc) {
   const vh_sh::Half *T = vt.half + ((int64_t)p * 2 * vt.cap + t) * 4;
   const int32_t *order = vt.order + (int64_t)p * vt.cap;
-  const int32_t a = order[T[0].p], b = order[T[1].p], c = order[T[2].p];  // corner ranks -> matches
+  a = order[T[0].p]; b = order[T[1].p]; c = order[T[2].p];  // corner ranks -> matches
   const float2 *flow = vt.flow + (int64_t)p * vt.cap;
   const float2 fa = flow[a], fb = flow[b], fc = flow[c];
   const float tol = 5;  // hard-coded in the reference (:34), not parameters::outlier_flow_tolerance
   const int32_t ab = fabsf(fa.x - fb.x) + fabsf(fa.y - fb.y) < tol ? 1 : 0;
   const int32_t bc = fabsf(fb.x - fc.x) + fabsf(fb.y - fc.y) < tol ? 1 : 0;
   const int32_t ac = fabsf(fa.x - fc.x) + fabsf(fa.y - fc.y) < tol ? 1 : 0;
+  va = ab + ac; vb = ab + bc; vc = bc + ac;
+}
+
+// lists of up to 16 384 records: one workgroup per list, the counters in LDS (54 k votes per KITTI list: as global
+// atomics they were the whole kernel), written out once
+__global__ __launch_bounds__(1024) void vote_tally_kernel(VhVote vt) {
+  extern __shared__ int32_t sv[];
+  const int32_t p = blockIdx.x;
+  const VhVoteMeta &m = vt.meta[p];
+  if (m.status != VH_VOTE_OK) return;
+  const int32_t n = m.n, ntri = m.ntri;
+  for (int32_t i = threadIdx.x; i < n; i += 1024) sv[i] = 0;
+  __syncthreads();
+  for (int32_t t = threadIdx.x; t < ntri; t += 1024) {
+    int32_t a, b, c, va, vb, vc;
+    tally_triangle(vt, p, t, a, b, c, va, vb, vc);
+    if (va) atomicAdd(&sv[a], va);
+    if (vb) atomicAdd(&sv[b], vb);
+    if (vc) atomicAdd(&sv[c], vc);
+  }
+  __syncthreads();
   int32_t *votes = vt.votes + (int64_t)p * vt.cap;
-  if (ab + ac) atomicAdd(&votes[a], ab + ac);
-  if (ab + bc) atomicAdd(&votes[b], ab + bc);
-  if (bc + ac) atomicAdd(&votes[c], bc + ac);
+  for (int32_t i = threadIdx.x; i < n; i += 1024) votes[i] = sv[i];
+}
+
+// longer lists: a thread per triangle, global counters (zeroed by vote_prep)
+__global__ __launch_bounds__(256) void vote_tally_global_kernel(VhVote vt) {
+  const int32_t p = blockIdx.y;
+  const VhVoteMeta &m = vt.meta[p];
+  if (m.status != VH_VOTE_OK) return;
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= m.ntri) return;
+  int32_t a, b, c, va, vb, vc;
+  tally_triangle(vt, p, t, a, b, c, va, vb, vc);
+  int32_t *votes = vt.votes + (int64_t)p * vt.cap;
+  if (va) atomicAdd(&votes[a], va);
+  if (vb) atomicAdd(&votes[b], vb);
+  if (vc) atomicAdd(&votes[c], vc);
 }
 
 // ---- vote_select -------------------------------------------------------------------------------------
@@ -431,6 +460,7 @@ void vh_launch_vote(const VhVote &vt, int32_t lanes, int32_t max_features, float
   static const int32_t prio = [] { const char *e = getenv("VH_VOTE_PRIO"); return e ? atoi(e) : 3; }();
   hipLaunchKernelGGL(vote_sweep_kernel, dim3((vt.P + lanes - 1) / lanes), dim3(64), sizeof(int32_t) * (size_t)lanes * (vt.hsize + VH_VOTE_PEND), st, vt, lanes, prio);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[1], st);
-  hipLaunchKernelGGL(vote_tally_kernel, dim3((2 * vt.cap + 255) / 256, vt.P), dim3(256), 0, st, vt);
+  if (vt.cap <= 16384) hipLaunchKernelGGL(vote_tally_kernel, dim3(vt.P), dim3(1024), sizeof(int32_t) * (size_t)vt.cap, st, vt);
+  else hipLaunchKernelGGL(vote_tally_global_kernel, dim3((2 * vt.cap + 255) / 256, vt.P), dim3(256), 0, st, vt);
   hipLaunchKernelGGL(vote_select_kernel, dim3(vt.P), dim3(64), 0, st, vt, max_features, bw, bh, lfsr, lfsr_n, out, out_cap, out_count);
 }

@@ -397,9 +397,9 @@ int32_t vh_group_estimate_motion_mono(vh_group *g, const vh_mono_params *e, cons
 /* ---- the same chain ON THE DEVICE: no host work between matching and the pose (csrc/kernels_vote.hip) ----
  * removeOutliers' Delaunay triangulation is a sequential chain per match list (csrc/sweep_hull.h); on the GPU a list
  * takes tens of milliseconds as one lane, and the throughput comes from the lists in flight:
- *   vh_group_post_device_config  steps_per_batch (1..64) steps are voted on by one kernel sequence (steps_per_batch * S
- *                         lists), up to `batches` (1..64) such batches are in flight on low-priority streams beside the
- *                         matcher's own kernels; lanes_per_wave (1..64) lists share a wavefront.  Default 64, 3, 64 (a batch takes
+ *   vh_group_post_device_config  steps_per_batch (1..256) steps are voted on by one kernel sequence (steps_per_batch * S
+ *                         lists, at most 65 535: beyond that vh_group_post_begin_device returns VH_ERR_UNSUPPORTED), up to `batches` (1..64) such batches are in flight on low-priority streams beside the
+ *                         matcher's own kernels; lanes_per_wave (1..64) lists share a wavefront.  Default 64, 3, 16 (a batch takes
  *                         0.4-0.5 s whatever its size: the rate is steps in flight over that latency).
  *                         VH_ERR_STATE while steps are in flight.
  *   vh_group_post_begin_device   after vh_group_match_features: the step's S lists leave the matcher's buffer for the

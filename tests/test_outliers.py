@@ -355,6 +355,18 @@ def test_device_vote_equals_the_reference_fixtures_and_the_oracle(lanes, pkg, or
 
 
 @pytest.mark.gpu
+def test_device_vote_beyond_the_lds_tally(pkg, oracle, gpu):
+    """Lists of more than 16 384 records (beyond the reference's own POINT_L = 14002 arrays, and beyond the per-list
+    vote counters the tally keeps in LDS): the thread-per-triangle tally with global counters."""
+    rng = np.random.default_rng(23)
+    lists = [random_matches(pkg, rng, n, W=1920, H=1080) for n in (20000, 16385, 700)]
+    got, _, _ = pkg.remove_outliers_device(lists, lanes_per_wave=2)
+    for g, pm in zip(got, lists):
+        assert g.tobytes() == oracle.remove_outliers(pm)[0].tobytes()
+    assert 5000 < len(got[0]) < 20000
+
+
+@pytest.mark.gpu
 def test_device_vote_refuses_what_it_cannot_triangulate(pkg, gpu):
     rng = np.random.default_rng(22)
     pm = random_matches(pkg, rng, 50)
