@@ -524,3 +524,18 @@ def test_device_post_stage_leaves_stereo_lists_unvoted(pkg, ob, oracle, gpu):
         g.postBeginDevice(4096, 2, 0.25, 50.0)  # a bucket below one pixel
     assert ex.value.code == pkg.VH_ERR_INVALID_ARG
     g.close()
+
+
+@pytest.mark.gpu
+def test_device_post_stage_time_sliced(gpu):
+    """VH_VOTE_SERIAL=1 (csrc/engine.hip vote_launch: the matcher's next step waits for the batch's vote instead of
+    running beside it; an experiment switch, profiles/EXPERIMENTS.md): the same results -- the device post-stage tests
+    of this file once more on that path."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VH_VOTE_SERIAL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "device_post_stage and not time_sliced"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
