@@ -114,9 +114,36 @@ __device__ __forceinline__ int32_t scan_exclusive(int32_t n, int32_t *sWave, Loa
   return carry;
 }
 
+// Query tiles of the flow search: <= VH_TILE_Q consecutive features of one class in SNAKE order -- the (class, u-bin)
+// columns one after the other, even columns in ascending bin order (ascending v), odd columns descending -- so that
+// the lanes of every wave are filled (only the last tile of a class is partial) AND a tile that runs from the end of
+// one column into the next stays compact: it holds the bottoms (or the tops) of two neighbouring columns.  Tiles cut
+// at column ends instead leave ~10 % of the lanes idle; tiles over plain bin order make every crossing tile span the
+// whole image height (tools/tile_model.py: evaluated / in-window pairs 1.40 / 1.38 / 1.32 at KITTI size).
+// A tile record is {first snake index, end, class, column of the first index}; a snake index k inside column
+// [A, B) of the bin order is the position k (even column) or A + B - 1 - k (odd column): kernels_match.hip.
+// One lane per (class, column) writes the tiles that start inside its column.
+__device__ __forceinline__ void make_tiles(const VhSets &s, const int32_t *__restrict__ bs, int32_t set) {
+  const int32_t span = s.ubn * s.vbn;
+  int32_t tb[5];
+  tb[0] = 0;
+#pragma unroll
+  for (int32_t c = 0; c < 4; c++) tb[c + 1] = tb[c] + (bs[(c + 1) * span] - bs[c * span] + VH_TILE_Q - 1) / VH_TILE_Q;
+  int4 *__restrict__ tiles = s.tiles + (int64_t)set * s.max_tiles;
+  for (int32_t i = threadIdx.x; i < 4 * s.ubn; i += VH_SCAN_T) {
+    const int32_t c = i / s.ubn, col = i - c * s.ubn;
+    const int32_t cls0 = bs[c * span], cls1 = bs[(c + 1) * span];
+    const int32_t a = bs[(c * s.ubn + col) * s.vbn] - cls0, b = bs[(c * s.ubn + col + 1) * s.vbn] - cls0;
+    for (int32_t t = (a + VH_TILE_Q - 1) / VH_TILE_Q; t * VH_TILE_Q < b; t++) {
+      const int32_t k0 = cls0 + t * VH_TILE_Q, slot = tb[c] + t;
+      if (slot < s.max_tiles) tiles[slot] = make_int4(k0, min(cls1, k0 + VH_TILE_Q), c, col);
+    }
+  }
+  if (threadIdx.x == 0) s.tile_cnt[set] = min(tb[4], s.max_tiles);
+}
+
 // One workgroup per set: exclusive scan of the histogram into bin_start, and
-// the list of query tiles (<= VH_TILE_Q consecutive bin-ordered features of one
-// (class, u-bin) column) the match kernel works through.
+// the list of query tiles the match kernel works through (make_tiles).
 __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t set0) {
   __shared__ int32_t sWave[VH_SCAN_T / 64];
   const int32_t set = set0 + blockIdx.x, tid = threadIdx.x;
@@ -127,24 +154,7 @@ __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t s
   if (tid == 0) bs[s.nbins] = nfeat;
   __syncthreads();  // bin_start is read back below by other lanes
 
-  // query tiles: <= VH_TILE_Q consecutive bin-ordered queries of one tile group.  A
-  // group is one (class, u-bin) column, or -- when the v search window covers
-  // the whole image anyway (2*radius >= H), so that mixing columns cannot widen
-  // the v range a wave has to walk -- a whole class, which fills the lanes of
-  // almost every wave (column remainders would leave ~25 % of them idle).
-  const int32_t ngroup = s.nbins / s.tile_span;
-  int4 *__restrict__ tiles = s.tiles + (int64_t)set * s.max_tiles;
-  // one group per lane: the per-group tile writes below then spread over the lanes
-  const int32_t ntile = scan_exclusive<1>(
-      ngroup, sWave,
-      [&](int32_t grp) { return (bs[(grp + 1) * s.tile_span] - bs[grp * s.tile_span] + VH_TILE_Q - 1) / VH_TILE_Q; },
-      [&](int32_t grp, int32_t t0, int32_t nt) {
-        const int32_t q0 = bs[grp * s.tile_span], q1 = bs[(grp + 1) * s.tile_span];
-        const int32_t cls = (grp * s.tile_span) / (s.ubn * s.vbn);
-        for (int32_t k = 0; k < nt; k++, t0++)
-          if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + VH_TILE_Q * k, min(q1, q0 + VH_TILE_Q * k + VH_TILE_Q), cls, 0);
-      });
-  if (tid == 0) s.tile_cnt[set] = min(ntile, s.max_tiles);
+  make_tiles(s, bs, set);
 
   // row index: exclusive scan of the (class, v) histogram
   const int32_t nrow = 4 * s.H;
@@ -238,19 +248,7 @@ __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_ordered_kernel(VhSets s, V
   if (tid == 0) bs[s.nbins] = nfeat;
   __syncthreads();  // bin_start is read back below by other lanes
 
-  // query tiles (as bin_scan_kernel)
-  const int32_t ngroup = s.nbins / s.tile_span;
-  int4 *__restrict__ tiles = s.tiles + (int64_t)set * s.max_tiles;
-  const int32_t ntile = scan_exclusive<1>(
-      ngroup, sWave,
-      [&](int32_t grp) { return (bs[(grp + 1) * s.tile_span] - bs[grp * s.tile_span] + VH_TILE_Q - 1) / VH_TILE_Q; },
-      [&](int32_t grp, int32_t t0, int32_t nt) {
-        const int32_t q0 = bs[grp * s.tile_span], q1 = bs[(grp + 1) * s.tile_span];
-        const int32_t cls = (grp * s.tile_span) / (s.ubn * s.vbn);
-        for (int32_t k = 0; k < nt; k++, t0++)
-          if (t0 < s.max_tiles) tiles[t0] = make_int4(q0 + VH_TILE_Q * k, min(q1, q0 + VH_TILE_Q * k + VH_TILE_Q), cls, 0);
-      });
-  if (tid == 0) s.tile_cnt[set] = min(ntile, s.max_tiles);
+  make_tiles(s, bs, set);
 }
 
 __global__ void bin_fill_kernel(VhSets s, int32_t set0) {

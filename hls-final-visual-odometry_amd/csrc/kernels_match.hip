@@ -50,6 +50,9 @@ extern "C" int32_t vh_debug_flow_stats(unsigned long long *out, int32_t reset) {
 #ifndef VH_MATCH_WAVES
 #define VH_MATCH_WAVES 7
 #endif
+#ifndef VH_SNAKE
+#define VH_SNAKE 1  // 0 (experiments): query tiles over the plain bin order
+#endif
 
 namespace {
 
@@ -163,6 +166,86 @@ __device__ __forceinline__ void walk_region(const VhSets &s, const int32_t *__re
       int32_t pa0 = 1, pa1 = 0;
       if (TESTED) { pa0 = __builtin_amdgcn_readlane(t_a0, c_ci); pa1 = __builtin_amdgcn_readlane(t_a1, c_ci); }
       consume(c_pc, c_p1, pa0, pa1, c_pl, c_gu, c_g0, c_g1);
+      if (!more) break;
+    }
+  }
+}
+
+// LDS-DMA (gfx950 global_load_lds_*): a wave-instruction copies 64 x 16 (or 4) bytes from per-lane global
+// addresses straight to LDS at M0 + lane * size -- no VGPR destination, no ds_write.  hipcc does not count an asm
+// memory operation, so completion is waited for by hand (vmcnt) before the chunk is read; the builtin form makes
+// hipcc drain every DMA (vmcnt(0)) before ANY ds_read, which would serialise the prefetch of the next chunk.
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p);
+}
+
+// walk_region for the flow tiles (the stream is consumed from LDS): the same chunk cursor, but the records of a
+// chunk travel global -> LDS by LDS-DMA into one of two wave-private buffers (wD: 2 x {64 first halves | 64 second
+// halves}, wU: 2 x 64 u|v<<16 words, TESTED only), chunk k+1 in flight while `consume` reads chunk k.  No staging
+// registers, no register copies of a software pipeline, no ds_write: ~10 instead of ~35 VALU instructions per chunk.
+//   consume(pc, p1, pa0, pa1, cD, cU): chunk [pc, min(pc+64, p1)) staged at cD / cU (slot j: candidate min(pc+j, p1-1))
+template <bool TESTED, class Consume>
+__device__ __forceinline__ void walk_region_lds(const VhSets &s, const int32_t *__restrict__ cbs, const uint32_t *__restrict__ cuv,
+                                                const uint4 *__restrict__ cdesc, int32_t c, int32_t UB0, int32_t UB1, int32_t VB0,
+                                                int32_t VB1, int32_t ULO_MAX, int32_t UHI_MIN, int32_t VA0, int32_t VA1,
+                                                uint4 *wD, uint32_t *wU, Consume consume) {
+  const int32_t lane = threadIdx.x & 63;
+  const uint32_t ldsD = lds_addr(wD), ldsU = lds_addr(wU);
+  const bool merged = !TESTED && VB0 == 0 && VB1 == s.vbn - 1;
+  const int32_t UB1w = merged ? UB0 : UB1;
+  for (int32_t cb = UB0; cb <= UB1w; cb += 64) {
+    const int32_t ncb = min(64, UB1w - cb + 1);
+    int32_t t_p0 = 0, t_p1 = 0, t_a0 = 0, t_a1 = 0;
+    if (lane < ncb) {
+      const int32_t row = (c * s.ubn + cb + lane) * s.vbn;
+      t_p0 = cbs[row + VB0]; t_p1 = merged ? cbs[(c * s.ubn + UB1 + 1) * s.vbn] : cbs[row + VB1 + 1];
+      if (TESTED) {
+        const int32_t ubx = cb + lane;
+        const bool in_ = ubx * s.binsize >= ULO_MAX && ubx * s.binsize + s.binsize - 1 <= UHI_MIN;
+        t_a0 = in_ ? ((VA0 <= VA1) ? cbs[row + VA0] : t_p1) : 1;
+        t_a1 = in_ ? ((VA0 <= VA1) ? cbs[row + VA1 + 1] : t_p1) : 0;
+      }
+    }
+    int32_t ci = -1, pc = -64, p1 = 0;
+    const auto advance = [&]() -> bool {
+      pc += 64;
+      while (pc >= p1) {
+        if (++ci >= ncb) return false;
+        pc = __builtin_amdgcn_readlane(t_p0, ci); p1 = __builtin_amdgcn_readlane(t_p1, ci);
+      }
+      return true;
+    };
+    const auto issue = [&](int32_t b) {  // chunk [pc, p1) -> buffer b
+      const int32_t pl = min(pc + lane, p1 - 1);
+      const uint4 *g = cdesc + 2 * (int64_t)pl;
+      glds16(g, ldsD + (uint32_t)b * 2048u); glds16(g + 1, ldsD + (uint32_t)b * 2048u + 1024u);
+      if (TESTED) glds4(cuv + pl, ldsU + (uint32_t)b * 256u);
+    };
+    if (!advance()) continue;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of the buffers by an earlier walk has returned
+    int32_t buf = 0;
+    issue(0);
+    for (;;) {
+      const int32_t c_pc = pc, c_p1 = p1, c_ci = ci, c_buf = buf;
+      const bool more = advance();
+      if (more) {
+        buf ^= 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk k-1, the last reader of this buffer, is consumed
+        issue(buf);
+        if (TESTED) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // chunk k has landed (k+1 may be in flight)
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      int32_t pa0 = 1, pa1 = 0;
+      if (TESTED) { pa0 = __builtin_amdgcn_readlane(t_a0, c_ci); pa1 = __builtin_amdgcn_readlane(t_a1, c_ci); }
+      consume(c_pc, c_p1, pa0, pa1, (const uint4 *)(wD + c_buf * 128), (const uint32_t *)(wU + c_buf * 64));
       if (!more) break;
     }
   }
@@ -436,7 +519,7 @@ __device__ __forceinline__ void finish_tile(const VhSets &s, const VhMatchArgs &
 // outward to whole trips of 2*P candidates without any tail code.
 template <int Q, int P, int KM, bool SPEC>
 __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a, int32_t pass, int32_t stream,
-                                          int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c,
+                                          int32_t qset, int32_t cset, int32_t q0, int32_t q1, int32_t c, int32_t col0,
                                           int32_t pbase, int32_t pcnt, uint4 *wD, uint32_t *wU, TileOut<Q> &out) {
   constexpr int L = 64 / P;
   static_assert(L == 8 || L == 16, "every 16-lane row must hold the whole tile (row-wise window reduction)");
@@ -458,11 +541,37 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
   const key_t KNONE = (key_t)~(key_t)0;
   key_t best_key[Q];
   int32_t umin = 0x7FFFFFFF, umax = -1, vmin = 0x7FFFFFFF, vmax = -1;
+  // [q0, q1) are SNAKE indices (kernels_bin.hip: make_tiles): inside the column [A, B) of the query set's bin order
+  // the index k is the position k (even column) or A + B - 1 - k (odd column).  Column starts from col0 on, one per lane.
+  int32_t qp[Q];
 #pragma unroll
   for (int32_t qi = 0; qi < Q; qi++) {
     const int32_t q = q0 + L * qi + l;
     valid[qi] = q < q1;
-    const int32_t ql = valid[qi] ? q : q0;
+    qp[qi] = valid[qi] ? q : q0;
+  }
+  {
+    const int32_t *__restrict__ qbs = s.bin_start + (int64_t)qset * (s.nbins + 1);
+    int32_t colb = col0, j = 0;
+    int32_t csv = qbs[(c * s.ubn + min(colb + lane, s.ubn)) * s.vbn];
+    int32_t A = __builtin_amdgcn_readlane(csv, 0);
+    int32_t k[Q];
+#pragma unroll
+    for (int32_t qi = 0; qi < Q; qi++) k[qi] = qp[qi];
+    for (;;) {
+      const int32_t B = __builtin_amdgcn_readlane(csv, j + 1);
+      if (VH_SNAKE && ((colb + j) & 1)) {
+#pragma unroll
+        for (int32_t qi = 0; qi < Q; qi++) if (k[qi] >= A && k[qi] < B) qp[qi] = A + B - 1 - k[qi];
+      }
+      if (B >= q1 || colb + j + 1 >= s.ubn) break;  // (wave-uniform)
+      A = B;
+      if (++j == 63) { colb += 63; j = 0; csv = qbs[(c * s.ubn + min(colb + lane, s.ubn)) * s.vbn]; }
+    }
+  }
+#pragma unroll
+  for (int32_t qi = 0; qi < Q; qi++) {
+    const int32_t ql = qp[qi];
     uv1[qi] = quv[ql];
     a0[qi] = qdesc[2 * (int64_t)ql]; a1[qi] = qdesc[2 * (int64_t)ql + 1];
     const int32_t u1 = uv1[qi] & 0xFFFF, v1 = uv1[qi] >> 16;
@@ -516,17 +625,13 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
     return (TEST != 0 && out) ? KNONE : key;
   };
   VH_STAT(0, 1); VH_STAT(5, q1 - q0); VH_STAT(6, UB1 - UB0 + 1);
-  walk_region<!SPEC, !SPEC>(s, cbs, cuv, cdesc, c, UB0, UB1, VB0, VB1, ULO_MAX, UHI_MIN, VA0, VA1,
-    [&](int32_t pc, int32_t p1, int32_t pa0, int32_t pa1, int32_t, uint32_t gu, const uint4 &g0, const uint4 &g1) {
+  walk_region_lds<!SPEC>(s, cbs, cuv, cdesc, c, UB0, UB1, VB0, VB1, ULO_MAX, UHI_MIN, VA0, VA1, wD, wU,
+    [&](int32_t pc, int32_t p1, int32_t pa0, int32_t pa1, const uint4 *cD, const uint32_t *cU) {
       VH_STAT(1, 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous chunk fully consumed
-      wD[lane] = g0; wD[64 + lane] = g1;
-      if (!SPEC) wU[lane] = gu;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // chunk visible to every lane of the wave
       const int32_t mcnt = min(64, p1 - pc);
       const int32_t jend = (mcnt + TRIP - 1) & ~(TRIP - 1);  // <= 64: trailing slots hold copies of the last candidate
-      const uint4 *rd = wD + ph;                              // this phase's slot of step 0 (second half: +64)
-      const uint32_t *ru = wU + ph;
+      const uint4 *rd = cD + ph;                              // this phase's slot of step 0 (second half: +64)
+      const uint32_t *ru = cU + ph;
       uint32_t seedA = (uint32_t)(pc - pbase + ph), seedB = seedA + P;
       int32_t j = 0;
       // one trip: candidates (j + ph) and (j + P + ph) at slot offset `o` of this phase's read pointers
@@ -574,7 +679,7 @@ __device__ __forceinline__ void flow_tile(const VhSets &s, const VhMatchArgs &a,
 #pragma unroll
     for (int32_t d = L; d < 64; d <<= 1) k = min(k, shfl_xor_u64(k, d));
     out.k[qi] = k; out.a0[qi] = a0[qi]; out.a1[qi] = a1[qi]; out.uv1[qi] = uv1[qi]; out.valid[qi] = valid[qi];
-    out.qpos[qi] = valid[qi] ? q0 + L * qi + l : q0;
+    out.qpos[qi] = qp[qi];
   }
 }
 
@@ -586,16 +691,16 @@ __device__ __forceinline__ void flow_pass(const VhSets &s, const VhMatchArgs &a,
        tile += gridDim.x * 4) {
     const int4 t = s.tiles[(int64_t)qset * s.max_tiles + tile];
     const int32_t q0 = __builtin_amdgcn_readfirstlane(t.x), q1 = __builtin_amdgcn_readfirstlane(t.y);
-    const int32_t c = __builtin_amdgcn_readfirstlane(t.z);
+    const int32_t c = __builtin_amdgcn_readfirstlane(t.z), col0 = __builtin_amdgcn_readfirstlane(t.w);
     // candidates of class c occupy the contiguous positions [pbase, pend) of the bin order
     const int32_t *cbs = s.bin_start + (int64_t)cset * (s.nbins + 1);
     const int32_t pbase = __builtin_amdgcn_readfirstlane(cbs[c * s.ubn * s.vbn]);
     const int32_t pend = __builtin_amdgcn_readfirstlane(cbs[(c + 1) * s.ubn * s.vbn]);
     const int32_t km = key_mode_of(pend - pbase, a.wide_keys);
     TileOut<VH_FLOW_Q> out;
-    if (km == KEY_HI16) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, out);
-    else if (km == KEY_W19) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, out);
-    else flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, pbase, pend - pbase, wD, wU, out);
+    if (km == KEY_HI16) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_HI16, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, col0, pbase, pend - pbase, wD, wU, out);
+    else if (km == KEY_W19) flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_W19, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, col0, pbase, pend - pbase, wD, wU, out);
+    else flow_tile<VH_FLOW_Q, VH_FLOW_P, KEY_64, SPEC>(s, a, pass, stream, qset, cset, q0, q1, c, col0, pbase, pend - pbase, wD, wU, out);
     finish_tile<VH_FLOW_Q, VH_FLOW_P, SPEC, true>(s, a, pass, stream, qset, cset, c, pbase, pend - pbase, out, best, redo_count);
   }
 }
@@ -750,15 +855,15 @@ __device__ __forceinline__ void rows_pass(const VhSets &s, const VhMatchArgs &a,
 template <bool SPEC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VH_MATCH_WAVES, 8)))
 match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best, int32_t *__restrict__ redo) {
-  __shared__ uint4 sDesc[4 * 128];   // per wave: 64 staged candidates, first | second descriptor half
-  __shared__ uint32_t sAux[4 * 64];  // per wave: their u | v << 16 (tested flow loop) or key seeds (stereo)
+  __shared__ uint4 sDesc[4 * 256];   // per wave: 2 buffers of 64 staged candidates, first | second descriptor half
+  __shared__ uint32_t sAux[4 * 128]; // per wave: 2 x their u | v << 16 (tested flow loop) or key seeds (stereo)
   __shared__ uint32_t sAux2[SPEC ? 1 : 4 * 64];  // per wave: u | v << 16 (tested stereo loop)
   const int32_t pass = blockIdx.y, stream = blockIdx.z;
   if (a.prior && pass == 1) return;  // (searched per driving feature, with its prediction: kernels_prior.hip)
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
-  uint4 *wD = sDesc + (threadIdx.x >> 6) * 128;
-  uint32_t *wU = sAux + (threadIdx.x >> 6) * 64;
+  uint4 *wD = sDesc + (threadIdx.x >> 6) * 256;
+  uint32_t *wU = sAux + (threadIdx.x >> 6) * 128;
   uint32_t *wV = sAux2 + (SPEC ? 0 : (threadIdx.x >> 6) * 64);
   // queries searched again by this stream's speculative passes: read by the host (with a lag) to
   // choose between the speculative and the tested loops (engine.hip: match policy)
