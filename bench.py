@@ -50,30 +50,33 @@ NOISE = 0  # --noise: grey levels of uniform sensor noise added to every frame (
 NOISE_FRAC = 1.0  # --noise-frac: share of the pixels that receive it
 
 
-def make_frames(pkg, n_streams: int, n_frames: int, rank: int):
-    """[T][2][S][H][bpl] uint8: stream s follows sequence (seed 1 + (rank*S+s) % 8),
+def make_frames(pkg, n_streams: int, n_frames: int, rank: int, size=None, noise=None, noise_frac=None, n_seeds: int = 8):
+    """[T][2][S][H][bpl] uint8: stream s follows sequence (seed 1 + (rank*S+s) % n_seeds),
     phase-shifted so that no two streams of a rank see identical frames."""
-    bpl = pkg.synth.bytes_per_line(W)
-    out = np.zeros((n_frames, 2, n_streams, H, bpl), np.uint8)
-    cache = {}  # (seed, k) -> (left, right): streams 8 apart share the sequence, shifted in time
+    w, h = size if size else (W, H)
+    noise = NOISE if noise is None else noise
+    noise_frac = NOISE_FRAC if noise_frac is None else noise_frac
+    bpl = pkg.synth.bytes_per_line(w)
+    out = np.zeros((n_frames, 2, n_streams, h, bpl), np.uint8)
+    cache = {}  # (seed, k) -> (left, right): streams n_seeds apart share the sequence, shifted in time
 
     def pair(seed, k):
         if (seed, k) not in cache:
             dx, dy = (5 * k) % 20, k % 20
-            pr = [pkg.synth.frame(W, H, dx, dy, 8, 1, seed), pkg.synth.frame(W, H, dx + 12, dy, 8, 1, seed)]
-            if NOISE:
+            pr = [pkg.synth.frame(w, h, dx, dy, 8, 1, seed), pkg.synth.frame(w, h, dx + 12, dy, 8, 1, seed)]
+            if noise:
                 rng = np.random.default_rng(seed * 1000 + k)
                 for i_ in range(2):
-                    nz = rng.integers(-NOISE, NOISE + 1, pr[i_].shape)
-                    if NOISE_FRAC < 1.0:
-                        nz = nz * (rng.random(pr[i_].shape) < NOISE_FRAC)
+                    nz = rng.integers(-noise, noise + 1, pr[i_].shape)
+                    if noise_frac < 1.0:
+                        nz = nz * (rng.random(pr[i_].shape) < noise_frac)
                     im = np.clip(pr[i_].astype(np.int32) + nz, 0, 255).astype(np.uint8)
-                    im[:, W:] = 0
+                    im[:, w:] = 0
                     pr[i_] = im
             cache[(seed, k)] = tuple(pr)
         return cache[(seed, k)]
 
-    for s, (gs, seed, phase) in enumerate(stream_assignment(rank, n_streams)):
+    for s, (gs, seed, phase) in enumerate(stream_assignment(rank, n_streams, n_seeds)):
         for t in range(n_frames):
             out[t, 0, s], out[t, 1, s] = pair(seed, t + phase)
     return out, bpl
@@ -158,13 +161,13 @@ def nm_max_hint(grp) -> int:
     return int(nm.max()) if len(nm) else 0
 
 
-def stream_assignment(rank: int, n_streams: int):
+def stream_assignment(rank: int, n_streams: int, n_seeds: int = 8):
     """Global stream ids owned by `rank` and their (seed, phase): streams are
     independent camera sequences, sharded rank-major with no overlap."""
     out = []
     for s in range(n_streams):
         gs = rank * n_streams + s
-        out.append((gs, 1 + gs % 8, gs // 8))
+        out.append((gs, 1 + gs % n_seeds, gs // n_seeds))
     return out
 
 
@@ -284,6 +287,98 @@ def dist_selftest(args):
     proto.close()
 
 
+def context_workload(pkg, torch, dev, local_rank, name, noise, ob=None, steps=5, blocks=3, warmup=6):
+    """A short run of another BASELINE.json config (or of the KITTI config with sensor noise) for the default line's
+    `other_workloads` key: a few steps x 3 blocks, the search kernel's share of the HBM yardstick from HIP events, and
+    stream 0's last step checked against the oracle.  Context, never `value`."""
+    wl = WORKLOADS[name]
+    w, h, S, T = wl["W"], wl["H"], wl["streams"], 3
+    t_all = time.perf_counter()
+    frames_np, bpl = make_frames(pkg, S, T, 0, size=(w, h), noise=noise, noise_frac=1.0, n_seeds=8 if name == "kitti" else 2)
+    dims, stride = [w, h, bpl], h * bpl
+    frames = torch.from_numpy(frames_np).to(dev)
+    params = pkg.Params.default(**wl["params"])
+    grp = pkg.StreamGroup(S, params, device=local_rank, max_features=wl["cap"], max_matches=wl["cap"])
+    grp.setStream(torch.cuda.current_stream().cuda_stream)
+    k = 0
+
+    def step():
+        nonlocal k
+        grp.pushBackDevice(frames[k % T, 0].data_ptr(), frames[k % T, 1].data_ptr(), stride, dims, False)
+        grp.matchFeatures(pkg.METHOD_QUAD)
+        k += 1
+
+    def sync():
+        grp.synchronize(); torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    sync()
+    bs = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        bs.append(time.perf_counter() - t0)
+    dt = float(np.median(bs))
+    grp.profileReset(); grp.profileEnable(True)
+    for _ in range(steps):
+        step()
+    sync()
+    grp.profileEnable(False)
+    ms, n_ = grp.profileRead("match")
+    nf, nm = grp.getCounts()
+    nfm = nf.astype(np.float64).mean(axis=0)
+    B_pair = 2 * bpl * h + 48 * (nfm[2] + nfm[3]) + 48 * nfm.sum() + 48 * float(nm.mean())
+    spec, redo = grp.searchStats()
+    got0 = grp.getMatches(0)
+    last = (k - 1) % T
+    grp.close()
+    del frames
+    out = {"workload": wl["label"] + (f" + noise +-{noise}" if noise else ""), "noise": noise, "value": S * steps / dt, "unit": "pairs/s",
+           "ms_per_step": 1e3 * dt / steps, "streams": S, "steps": steps, "blocks_s": [round(b, 5) for b in bs],
+           "features_per_image": float(nfm.mean()), "matches_per_pair": float(nm.mean()),
+           "search_loop": "speculative" if spec else "tested", "queries_searched_again": redo}
+    if n_:
+        sec = 1e-3 * ms / n_
+        out["roofline"] = {"bound": "hbm", "kernel": "match", "achieved": S * B_pair / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": S * B_pair / sec / 1e9 / HBM_PEAK_GBS, "us_per_launch": 1e3 * sec}
+    if ob is not None:  # the oracle as checker: stream 0's last step
+        o = ob.Oracle(); p = ob.Params.default(**wl["params"])
+        f = [o.compute_features(p, frames_np[t_, c, 0], dims)[1] for t_ in ((last - 1) % T, last) for c in (0, 1)]
+        out["parity_checked"] = bool(got0.tobytes() == o.matching(p, dims, 2, *f).tobytes())
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: this process -- which has imported neither torch nor the HIP
+    library and never will -- starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as
+    a CHILD (no exec: a process that initialised the GPU must not be replaced, and this way the rule cannot be broken by
+    a later edit either), relays rank 0's single JSON line and returns the child's exit code.  Under an existing
+    launcher (RANK / WORLD_SIZE set) bench.py behaves as before."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    for ln in child.stdout.splitlines():  # anything else a rank printed goes to stderr: stdout carries ONE line
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if child.returncode == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    return child.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,7 +405,10 @@ def main():
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-stream pass that measures exclusive kernel durations")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="CPU-only rehearsal of the multi-rank plumbing (gloo): sharding, barrier, MAX-reduced timing")
+    ap.add_argument("--no-other", action="store_true", help="skip the short context runs of the other BASELINE configs (other_workloads)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     global W, H, NOISE, NOISE_FRAC
     NOISE = args.noise
     NOISE_FRAC = args.noise_frac
@@ -561,6 +659,17 @@ def main():
     last = (k - 1) % T
     got0 = grp.getMatches(0)
 
+    # ---- the other BASELINE.json configs and one noisy run, a few steps each (context keys of the N = 1 line, never `value`)
+    other = None
+    if rank == 0 and world == 1 and args.workload == "kitti" and not args.no_other and not NOISE:
+        other = {}
+        ob_ = None if args.no_cpu else entry.load_oracle()
+        for key, (name_, noise_) in (("1080p", ("1080p", 0)), ("4k", ("4k", 0)), ("kitti_noise1", ("kitti", 1))):
+            try:
+                other[key] = context_workload(pkg, torch, dev, local_rank, name_, noise_, ob=ob_)
+            except Exception as ex:  # a context run must never cost the line its headline
+                other[key] = {"error": f"{type(ex).__name__}: {ex}"}
+
     if rank == 0:
         pairs = world * S * args.steps
         value = pairs / dt
@@ -574,22 +683,29 @@ def main():
             sec = prof[dom]["us_per_launch"] * 1e-6
             achieved = S * B_pair / sec / 1e9
             # HBM bytes of that kernel per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes
-            # (tools/profile_round.sh -> tools/summarize_profiles.py): reported only when they were
-            # taken on THIS build of the library (sha256) with this number of streams
-            traffic, traffic_src = None, None
+            # (tools/profile_round.sh -> tools/summarize_profiles.py): reported when they were taken on THIS code
+            # (sha256 of the sources that determine the code object -- the .so itself hashes differently on every
+            # rebuild) with this number of streams; traffic_step = sum over the step's kernels x launches
+            traffic, traffic_src, traffic_step = None, None, None
             tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tj):
                 try:
-                    import hashlib
                     tr = json.load(open(tj))
-                    lib_sha = hashlib.sha256(open(pkg.LIB_PATH, "rb").read()).hexdigest()
-                    if tr.get("streams") == S and tr.get("kernel") == dom and tr.get("lib_sha256") == lib_sha:
+                    src_sha = pkg.source_sha256()
+                    if tr.get("streams") == S and tr.get("kernel") == dom and tr.get("src_sha256") == src_sha:
                         traffic = tr.get("hbm_bytes_per_launch")
-                        traffic_src = f"profiles/traffic_latest.json ({tr.get('tag')}, lib {lib_sha[:12]})"
+                        traffic_src = f"profiles/traffic_latest.json ({tr.get('tag')}, sources {src_sha[:12]})"
+                        lps = {n_: v["launches"] / args.steps for n_, v in prof.items()}
+                        raw = sum(tr["per_kernel_raw"].get(n_, 0.0) * l_ for n_, l_ in lps.items())
+                        cor = sum(tr["per_kernel"].get(n_, 0.0) * l_ for n_, l_ in lps.items())
+                        traffic_step = {"unit": "bytes per step of S pairs", "raw": raw, "corrected_fetch_x2": cor,
+                                        "algorithmic": S * B_pair, "over_algorithmic_raw": raw / (S * B_pair),
+                                        "over_algorithmic_corrected": cor / (S * B_pair),
+                                        "hbm_frac_of_peak_corrected": cor / dt * args.steps / 1e9 / HBM_PEAK_GBS}
                     else:
-                        traffic_src = "profiles/traffic_latest.json is from another build or stream count: not reported"
-                except Exception:
-                    traffic = None
+                        traffic_src = "profiles/traffic_latest.json is from other sources or another stream count: not reported"
+                except Exception as ex:
+                    traffic, traffic_src = None, f"profiles/traffic_latest.json unreadable: {type(ex).__name__}"
             # What binds: the searches' compulsory v_sad_u8 work against the issue rate of that
             # instruction (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt: 4.27 SIMD cycles per
             # wave-instruction at >= 2 waves per SIMD, i.e. half rate, 5.26e11 wave-instructions/s over
@@ -609,7 +725,7 @@ def main():
                 if dom in prof_excl:
                     valu["frac_exclusive"] = sad_wave_instr / (prof_excl[dom]["us_per_launch"] * 1e-6) / peak
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_step": traffic_step,
                         "algorithmic_bytes_per_launch": S * B_pair, "us_per_launch": prof[dom]["us_per_launch"],
                         "us_per_launch_is": "overlapped with the other internal stream (as in the timed region)",
                         "binding_resource": "VALU issue of v_sad_u8 (half-rate instruction), not HBM",
@@ -628,7 +744,7 @@ def main():
                        "timed_seconds_total": round(float(np.sum(block_s)), 4)},
             "ranks_seen": ranks_seen,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["label"] + (f" + noise +-{NOISE}" if NOISE else ""),
+            "config": {"workload": wl["label"] + (f" + noise +-{NOISE}" if NOISE else ""), "noise": NOISE,
                        "streams_per_gpu": S, "frames_in_hbm": T, "features_per_image": float(nfm.mean()),
                        "matches_per_pair": float(nm.mean()), "parallelism": f"{world}x independent stream groups",
                        "device_mib_per_stream": round(grp.deviceBytes() / S / 2**20, 2)},
@@ -641,6 +757,7 @@ def main():
             "kernels_launches_per_step": {n_: round(v["launches"] / args.steps, 2) for n_, v in prof.items()},
             "kernels_us_per_launch_exclusive": {n_: round(v["us_per_launch"], 2) for n_, v in prof_excl.items()},
             "flow_pinned": flow,
+            "other_workloads": other,
             "e2e_matchfeatures": e2e,
             "e2e_matchfeatures_host_vote": e2e_host,
             "parity_scope": "primitives (computeFeatures, createIndexVector, findMatch, flow matching) pinned to the reference; "
@@ -677,4 +794,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -28,6 +28,24 @@ CHECK_LIB_PATH = os.path.join(HERE, "libviso_hip_check.so")  # the -DVH_CHECK bu
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
+
+
+def source_sha256() -> str:
+    """sha256 over what determines the code object: every source, header and the Makefile under csrc/ plus the public
+    header (names and contents, sorted).  Build-independent -- the `.so` hashes differently on every rebuild -- so a
+    profile (profiles/traffic_latest.json) can say which code it was taken on (bench.py: roofline.traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+             if f.endswith((".hip", ".h", ".hpp", ".cpp")) or f == "Makefile"]
+    files.append(os.path.join(INCLUDE, "viso_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 VH_OK = 0
 VH_ERR_INVALID_ARG, VH_ERR_NO_DEVICE, VH_ERR_HIP, VH_ERR_CAPACITY, VH_ERR_UNSUPPORTED, VH_ERR_STATE = -1, -2, -3, -4, -5, -6
 SET_1P, SET_2P, SET_1C, SET_2C = 0, 1, 2, 3
@@ -42,7 +60,7 @@ ABI_SYMBOLS = (
     "vh_group_create", "vh_group_destroy", "vh_group_streams", "vh_group_device_bytes", "vh_group_push_back_device",
     "vh_group_push_back", "vh_group_match_features", "vh_group_match_features_prior", "vh_group_remove_outliers", "vh_group_get_matches", "vh_group_get_matches_all", "vh_group_download_matches_async", "vh_group_wait_download", "vh_group_get_features",
     "vh_group_get_counts", "vh_group_synchronize", "vh_group_set_stream", "vh_group_clear_stream", "vh_group_stream_wait_images", "vh_group_profile_enable",
-    "vh_group_profile_read", "vh_group_profile_reset", "vh_group_debug_fail_next_alloc",
+    "vh_group_profile_read", "vh_group_profile_reset", "vh_group_debug_fail_next_alloc", "vh_debug_vote_stack_slots",
     "vh_default_ego_params", "vh_estimate_motion_stereo", "vh_group_estimate_motion", "vh_group_search_stats",
     "vh_default_mono_params", "vh_estimate_motion_mono", "vh_group_estimate_motion_mono",
     "vh_group_post_begin", "vh_group_post_finish", "vh_group_post_finish_mono",
@@ -167,7 +185,7 @@ def _lib():
             "vh_group_synchronize": [vp], "vh_group_set_stream": [vp, vp], "vh_group_clear_stream": [vp],
             "vh_group_stream_wait_images": [vp, vp],
             "vh_group_profile_enable": [vp, i32], "vh_group_profile_read": [vp, C.c_char_p, vp, vp],
-            "vh_group_profile_reset": [vp], "vh_group_debug_fail_next_alloc": [vp],
+            "vh_group_profile_reset": [vp], "vh_group_debug_fail_next_alloc": [vp], "vh_debug_vote_stack_slots": [i32],
             "vh_estimate_motion_stereo": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
             "vh_group_estimate_motion": [vp, vp, vp, vp, vp, vp],
             "vh_estimate_motion_mono": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -666,9 +684,10 @@ def remove_outliers(pm) -> np.ndarray:
 
 
 def remove_outliers_device(lists, lanes_per_wave: int = 1, max_features: int = 0, bucket_width: float = 50.0, bucket_height: float = 50.0,
-                           device: int = 0, out_cap: int = 0):
+                           device: int = 0, out_cap: int = 0, strict: bool = True):
     """removeOutliers (and bucketFeatures when max_features >= 1) of several match lists at once on the GPU
-    (vh_remove_outliers_device) -> (lists, triangles per list, sweep kernel ms)."""
+    (vh_remove_outliers_device) -> (lists, triangles per list, sweep kernel ms).  strict=False: an error code does not
+    raise; the healthy lists are returned (a refused list comes back empty) with the code as a fourth element."""
     lists = [np.ascontiguousarray(m, dtype=P_MATCH_DTYPE) for m in lists]
     n = len(lists)
     stride = max([len(m) for m in lists] + [1])
@@ -679,10 +698,13 @@ def remove_outliers_device(lists, lanes_per_wave: int = 1, max_features: int = 0
     out_cap = int(out_cap) if out_cap else stride
     out = np.zeros((n, out_cap), P_MATCH_DTYPE)
     oc = np.zeros(n, np.int32); ntri = np.zeros(n, np.int32); ms = C.c_float(0.0)
-    _check(_lib().vh_remove_outliers_device(device, n, _ptr(pm), stride, _ptr(counts), int(lanes_per_wave), int(max_features),
-                                            C.c_float(bucket_width), C.c_float(bucket_height), _ptr(out), out_cap, _ptr(oc), _ptr(ntri),
-                                            C.byref(ms)), "vh_remove_outliers_device")
-    return [out[l, :oc[l]].copy() for l in range(n)], ntri, ms.value
+    rc = _lib().vh_remove_outliers_device(device, n, _ptr(pm), stride, _ptr(counts), int(lanes_per_wave), int(max_features),
+                                          C.c_float(bucket_width), C.c_float(bucket_height), _ptr(out), out_cap, _ptr(oc), _ptr(ntri),
+                                          C.byref(ms))
+    if strict:
+        _check(rc, "vh_remove_outliers_device")
+        return [out[l, :oc[l]].copy() for l in range(n)], ntri, ms.value
+    return [out[l, :min(int(oc[l]), out_cap)].copy() for l in range(n)], ntri, ms.value, rc
 
 
 def match(param: Params, dims, method: int, m1p=None, m2p=None, m1c=None, m2c=None, device: int = 0, cap=None):

@@ -221,6 +221,7 @@ struct Group {
       sl.cap_ps = 0; sl.pending = false;
     }
     if (h_overflow) { (void)hipHostFree(h_overflow); h_overflow = nullptr; }
+    if (h_prior_tr) { (void)hipHostFree(h_prior_tr); h_prior_tr = nullptr; }
     allocated = false;
   }
 
@@ -653,6 +654,7 @@ struct Group {
 
   // tr16: null, or [S][16] row-major motion estimates for the quad method's prior (kernels_prior.hip); the intrinsics must be set
   double *d_prior_tr = nullptr;
+  double *h_prior_tr = nullptr;  // page-locked staging, two slots (one per table buffer): the caller's array is only borrowed
   int32_t match(int32_t method, const double *tr16 = nullptr) {
     if (method < 0 || method > 2) return VH_ERR_INVALID_ARG;
     if (!allocated || failed) return VH_ERR_STATE;
@@ -660,6 +662,7 @@ struct Group {
     if (tr16 && !(p.f > 0 && p.base > 0)) return VH_ERR_STATE;  // setIntrinsics first
     if (match_dirty) { const int32_t rr = match_recover(); if (rr) return rr; }
     if (tr16 && !d_prior_tr) { const int32_t rt = dmalloc(&d_prior_tr, 16 * (size_t)S, false); if (rt) { d_prior_tr = nullptr; return rt; } }
+    if (tr16 && !h_prior_tr) VH_HIP(hipHostMalloc((void **)&h_prior_tr, sizeof(double) * 2 * 16 * (size_t)S, hipHostMallocDefault));
     // everything that can fail without a kernel of the step in flight comes first
     bool fresh_mask = false;
     if (method == VH_METHOD_FLOW && !d_mask) {
@@ -686,7 +689,10 @@ struct Group {
     { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo + (size_t)buf * S, spec ? 1 : 0, ms); }
     VH_HIP(hipGetLastError());
     if (tr16) {  // hop 2 of the circle, per driving feature, behind the 1p -> 2p table of the launch above
-      VH_HIP(hipMemcpyAsync(d_prior_tr, tr16, sizeof(double) * 16 * (size_t)S, hipMemcpyHostToDevice, ms));
+      double *ht = h_prior_tr + (size_t)buf * 16 * S;
+      VH_HIP(hipEventSynchronize(ev_tables[buf]));  // (recorded behind the copy that last read this slot, two matches ago; at once if never recorded)
+      memcpy(ht, tr16, sizeof(double) * 16 * (size_t)S);
+      VH_HIP(hipMemcpyAsync(d_prior_tr, ht, sizeof(double) * 16 * (size_t)S, hipMemcpyHostToDevice, ms));
       { Scope sc(this, "quad_prior", ms); vh_launch_quad_prior(sets, a, d_prior_tr, p.f, p.cu, p.cv, p.base, d_best2[buf], ms); }
       VH_HIP(hipGetLastError());
     }
@@ -1112,6 +1118,7 @@ struct Group {
     bool has_ego = false, has_mono = false;
     vh_ego_params ego{}; vh_mono_params mono{};
     int32_t *d_rand = nullptr; size_t rand_per_step = 0;
+    int32_t *h_rand = nullptr; size_t h_rand_ints = 0;  // page-locked staging of the steps' random draws (the caller's array is only borrowed)
     double *d_xyz = nullptr, *d_tr = nullptr; int32_t *d_ok = nullptr; uint8_t *d_mono = nullptr;
     uint8_t *block = nullptr;  // d_rand | d_xyz | d_tr | d_ok | d_mono
     size_t block_bytes = 0;
@@ -1123,8 +1130,8 @@ struct Group {
       vb.release();
       if (block) (void)hipFree(block);
       block = nullptr; block_bytes = 0; d_rand = nullptr; d_xyz = nullptr; d_tr = nullptr; d_ok = nullptr; d_mono = nullptr;
-      for (void *q : {(void *)h_tr, (void *)h_ok, (void *)h_cnt, (void *)h_meta, (void *)h_out}) if (q) (void)hipHostFree(q);
-      h_tr = nullptr; h_ok = nullptr; h_cnt = nullptr; h_meta = nullptr; h_out = nullptr; h_lists = 0; h_out_cap = 0;
+      for (void *q : {(void *)h_tr, (void *)h_ok, (void *)h_cnt, (void *)h_meta, (void *)h_out, (void *)h_rand}) if (q) (void)hipHostFree(q);
+      h_tr = nullptr; h_ok = nullptr; h_cnt = nullptr; h_meta = nullptr; h_out = nullptr; h_lists = 0; h_out_cap = 0; h_rand = nullptr; h_rand_ints = 0;
       steps = 0; launched = false; busy = false; handed = 0;
     }
   };
@@ -1263,6 +1270,12 @@ struct Group {
       b->d_rand = (int32_t *)b->block; b->d_xyz = (double *)(b->block + b_rand); b->d_tr = (double *)(b->block + b_rand + b_xyz);
       b->d_ok = (int32_t *)(b->block + b_rand + b_xyz + b_tr); b->d_mono = b->block + b_rand + b_xyz + b_tr + b_ok;
       b->rand_per_step = rand_per_step;
+      if (b->h_rand_ints < rand_per_step * (size_t)vote_steps) {
+        if (b->h_rand) (void)hipHostFree(b->h_rand);
+        b->h_rand = nullptr; b->h_rand_ints = 0;
+        VH_HIP(hipHostMalloc((void **)&b->h_rand, sizeof(int32_t) * rand_per_step * (size_t)vote_steps, hipHostMallocDefault));
+        b->h_rand_ints = rand_per_step * (size_t)vote_steps;
+      }
       if (b->h_lists < P) {
         for (void *q : {(void *)b->h_tr, (void *)b->h_ok, (void *)b->h_cnt, (void *)b->h_meta}) if (q) (void)hipHostFree(q);
         b->h_tr = nullptr; b->h_ok = nullptr; b->h_cnt = nullptr; b->h_meta = nullptr;
@@ -1287,8 +1300,13 @@ struct Group {
     VH_HIP(hipStreamWaitEvent(down_stream, ev_post[last_buf], 0));
     vh_launch_vote_prep(b->vb.v, b->steps * S, S, (const vh_p_match *)d_matches, mcap, d_match_count, mcap, d_overflow, last_method != VH_METHOD_STEREO ? 1 : 0, down_stream);
     VH_HIP(hipGetLastError());
-    if (rand_per_step)
-      VH_HIP(hipMemcpyAsync(b->d_rand + rand_per_step * (size_t)b->steps, e ? rand3 : rand8, sizeof(int32_t) * rand_per_step, hipMemcpyHostToDevice, down_stream));
+    if (rand_per_step) {
+      // through the batch's page-locked slot of this step: an asynchronous copy from the caller's pageable array would
+      // make the host wait until the stream reaches it (behind the step's emission), and the array is only borrowed
+      int32_t *hr = b->h_rand + rand_per_step * (size_t)b->steps;
+      memcpy(hr, e ? rand3 : rand8, sizeof(int32_t) * rand_per_step);
+      VH_HIP(hipMemcpyAsync(b->d_rand + rand_per_step * (size_t)b->steps, hr, sizeof(int32_t) * rand_per_step, hipMemcpyHostToDevice, down_stream));
+    }
     VH_HIP(hipEventRecord(b->ev_prep, down_stream));
     VH_HIP(hipEventRecord(ev_down, down_stream)); ev_down_valid = true;
     VoteStep &st = vstep[(size_t)(post_dev_seq % (int64_t)vstep.size())];

@@ -147,6 +147,7 @@ __device__ __forceinline__ void make_tiles(const VhSets &s, const int32_t *__res
 __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t set0) {
   __shared__ int32_t sWave[VH_SCAN_T / 64];
   const int32_t set = set0 + blockIdx.x, tid = threadIdx.x;
+  VH_DET_SETPRIO();
   const int32_t *__restrict__ hist = s.hist + (int64_t)set * s.nbins;
   int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
   const int32_t nfeat = scan_exclusive<4>(s.nbins, sWave, [&](int32_t b) { return hist[b]; },
@@ -269,6 +270,7 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(VhSets s, int32_t set0, i
   const int32_t set = set0 + blockIdx.y;
   const int32_t bin = blockIdx.x * 16 + (threadIdx.x >> 4), gl = threadIdx.x & 15;
   if (bin >= s.nbins) return;
+  VH_DET_SETPRIO();
   const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
   const int32_t p0 = bs[bin], p1 = bs[bin + 1], L = p1 - p0;
   if (L <= 0) return;

@@ -267,10 +267,15 @@ template <int N> struct DetTile {
       if (seg_cost(px, s) < seg_cost(px, b)) b = s;
     return b;
   }
+#ifdef VH_DET_PX  // experiments: force the filter-pass layout (EXTRA="-DVH_DET_PX=4 -DVH_DET_SEG=4")
+  static constexpr int PX = VH_DET_PX;
+  static constexpr int SEG = VH_DET_SEG;
+#else
   static constexpr int PX = seg_cost(2, best_seg(2)) < seg_cost(4, best_seg(4)) ? 2 : 4;
+  static constexpr int SEG = best_seg(PX);
+#endif
   static constexpr int G = groups(PX);
   static constexpr int FP = PX * G;
-  static constexpr int SEG = best_seg(PX);
   static constexpr int ROWS = (FH + SEG - 1) / SEG;
   static constexpr int BIAS = 8192;  // stored responses are f + BIAS (positive int16; the NMS only compares)
   static_assert((G - 1) * PX / 4 + 1 <= DW - 1, "a group reads the staged dword it starts in and the next one");
@@ -284,6 +289,7 @@ __global__ void __launch_bounds__(256)
 detect_nms_fast_kernel(VhImages im, VhGeom g, uint64_t *__restrict__ rec, int32_t *__restrict__ chunk_count) {
   using T = DetTile<N>;
   constexpr int N1 = T::N1, WN = 2 * N + 1;
+  VH_DET_SETPRIO();
   constexpr int X_BYTES = (T::IH * T::IP > 6144) ? T::IH * T::IP : 6144;  // image tile, later queues (4 KB) + codes (2 KB)
   __shared__ __attribute__((aligned(16))) int16_t sF1[T::FH * T::FP];
   __shared__ __attribute__((aligned(16))) int16_t sF2[T::FH * T::FP];
@@ -616,6 +622,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const uint8_t *__restrict__ I = vh_image_ptr(im, id);
   const int32_t set = vh_image_set(im, id);
   const int32_t n1 = g.n + 1;
+  VH_DET_SETPRIO();
   VH_ETICK_INIT;
 
   // phase A: each lane owns VH_CHUNK/256 consecutive blocks; the four 16-bit codes of a

@@ -860,6 +860,9 @@ match_kernel(VhSets s, VhMatchArgs a, int32_t *__restrict__ best, int32_t *__res
   __shared__ uint32_t sAux2[SPEC ? 1 : 4 * 64];  // per wave: u | v << 16 (tested stereo loop)
   const int32_t pass = blockIdx.y, stream = blockIdx.z;
   if (a.prior && pass == 1) return;  // (searched per driving feature, with its prediction: kernels_prior.hip)
+#ifdef VH_EXP_SKIP  // timing-only builds (tools/ab_bench.sh): 1 = no stereo passes, 2 = no flow passes; results are wrong
+  if (VH_EXP_SKIP & (a.pass[pass].flow ? 2 : 1)) return;
+#endif
   const int32_t qset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].qset);
   const int32_t cset = vh_role_set(a.S, a.pair_cur, stream, a.pass[pass].cset);
   uint4 *wD = sDesc + (threadIdx.x >> 6) * 256;

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void vote_order_kernel(VhVote vt) {
 // `lanes` lists per wave, one per lane (the other lanes of the wave leave at once); the angular hash and the
 // flip stack of a lane's list live in LDS: lanes * (hsize + VH_VOTE_PEND) words of dynamic shared memory
 typedef __attribute__((address_space(3))) int32_t *LdsI32;
-__global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes, int32_t prio) {
+__global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes, int32_t prio, int32_t pend_cap) {
   extern __shared__ int32_t sweep_lds[];
   const int32_t lane = threadIdx.x;
   // a wave of this kernel lives for a hundred milliseconds beside thousands of short-lived ones of the matcher: with
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes
   sw.half = vt.half + (int64_t)p * 8 * vt.cap;
   sw.bucket = (LdsI32)(sweep_lds + lane * (vt.hsize + VH_VOTE_PEND));
   sw.pend = sw.bucket + vt.hsize;
-  sw.pend_cap = VH_VOTE_PEND;
+  sw.pend_cap = pend_cap;  // <= VH_VOTE_PEND, the slots the launch reserved
   sw.pts = (const Pt *)(vt.spts + (int64_t)p * vt.cap);
   sw.order = nullptr;  // (numbered in visiting order by vote_order)
   sw.n = m.n;
@@ -440,6 +440,14 @@ __global__ __launch_bounds__(64) void vote_select_kernel(VhVote vt, int32_t max_
 
 }  // namespace
 
+// test hook (include/viso_hip.h): flip-stack slots the sweep uses, so that the refusal path can be driven with ordinary lists
+static int32_t g_vote_pend_cap = VH_VOTE_PEND;
+extern "C" int32_t vh_debug_vote_stack_slots(int32_t slots) {
+  if (slots < 0 || slots > VH_VOTE_PEND + 1) return VH_ERR_INVALID_ARG;
+  g_vote_pend_cap = slots == 0 ? VH_VOTE_PEND : slots - 1;  // one more entry lives in a register
+  return VH_OK;
+}
+
 void vh_launch_vote_prep(const VhVote &vt, int32_t p0, int32_t S, const vh_p_match *src, int64_t src_stride, const int32_t *src_count, int32_t src_cap,
                          const int32_t *src_overflow, int32_t vote, hipStream_t st) {
   if (S < 1) return;
@@ -458,7 +466,7 @@ void vh_launch_vote(const VhVote &vt, int32_t lanes, int32_t max_features, float
   hipLaunchKernelGGL(vote_order_kernel, dim3(vt.P), dim3(64), 0, st, vt);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[0], st);
   static const int32_t prio = [] { const char *e = getenv("VH_VOTE_PRIO"); return e ? atoi(e) : 3; }();
-  hipLaunchKernelGGL(vote_sweep_kernel, dim3((vt.P + lanes - 1) / lanes), dim3(64), sizeof(int32_t) * (size_t)lanes * (vt.hsize + VH_VOTE_PEND), st, vt, lanes, prio);
+  hipLaunchKernelGGL(vote_sweep_kernel, dim3((vt.P + lanes - 1) / lanes), dim3(64), sizeof(int32_t) * (size_t)lanes * (vt.hsize + VH_VOTE_PEND), st, vt, lanes, prio, g_vote_pend_cap);
   if (sweep_ev) (void)hipEventRecord(sweep_ev[1], st);
   if (vt.cap <= 16384) hipLaunchKernelGGL(vote_tally_kernel, dim3(vt.P), dim3(1024), sizeof(int32_t) * (size_t)vt.cap, st, vt);
   else hipLaunchKernelGGL(vote_tally_global_kernel, dim3((2 * vt.cap + 255) / 256, vt.P), dim3(256), 0, st, vt);

@@ -198,7 +198,15 @@ struct Sweep {
           Hbl.twin = ar; half[bl].twin = ar;
           // push b0 + (b + 1) % 3
           if (depth > 0) {
-            if (depth - 1 < pend_cap) pend[depth - 1] = top; else overflow = 1;
+            if (depth - 1 < pend_cap) pend[depth - 1] = top;
+            else {
+              // The stack is full (the reference's has 13 slots and is undefined beyond).  The flip above is complete and
+              // the mesh consistent, but the edge `top` can no longer be remembered: STOP here -- nothing is popped and
+              // nothing more is written for this list (insert_all checks `overflow` after every legalisation), so a
+              // lost entry can never come back as an index.  The list is reported (VH_VOTE_STACK), not approximated.
+              overflow = 1;
+              return prev_half(a);
+            }
           }
           top = br;
           depth++;
@@ -211,7 +219,7 @@ struct Sweep {
         if (depth == 0) break;
         a = top;
         depth--;
-        if (depth > 0) top = depth - 1 < pend_cap ? pend[depth - 1] : kNone;
+        if (depth > 0) top = pend[depth - 1];  // (depth - 1 < pend_cap: a push beyond it ends the sweep)
         if (a == cb) { Ha = Cs; Hal = Cn; Har = Cp; }
         else {
 #ifdef VH_SH_STATS
@@ -304,6 +312,7 @@ struct Sweep {
       Half H0, H1, H2;
       int32_t t = emit(e, Pt{E.x, E.y}, i, q, f, Pt{F.x, F.y}, kNone, kNone, E.edge_of, H0, H1, H2);
       int32_t edge_i = legalize(t + 2, H2, H0, H1);
+      if (overflow) return;  // flip stack exhausted: the sweep ends here, the list is refused
       node[e].edge_of = t;
 
       // (a legalisation may have re-pointed edge_of of any hull node: it is read again where it is used)
@@ -316,6 +325,7 @@ struct Sweep {
         if (!turns_ccw(q, Pt{FW.x, FW.y}, Pt{F2.x, F2.y})) break;
         t = emit(fwd, Pt{FW.x, FW.y}, i, q, f2, Pt{F2.x, F2.y}, edge_i, kNone, eo_fwd, H0, H1, H2);
         edge_i = legalize(t + 2, H2, H0, H1);
+        if (overflow) return;
         node[fwd].next = fwd;  // off the hull
         fwd = f2;
         FW = F2;
@@ -328,6 +338,7 @@ struct Sweep {
           if (!turns_ccw(q, Pt{Bn.x, Bn.y}, Pt{E.x, E.y})) break;
           t = emit(b, Pt{Bn.x, Bn.y}, i, q, e, Pt{E.x, E.y}, kNone, eo_e, Bn.edge_of, H0, H1, H2);
           legalize(t + 2, H2, H0, H1);
+          if (overflow) return;
           node[b].edge_of = t;
           node[e].next = e;
           e = b;

@@ -47,6 +47,15 @@
 #endif
 #define VH_TILE_Q (64 * VH_FLOW_Q / VH_FLOW_P)  // queries per flow-search tile
 #define VH_NO_CODE 0xFFFFu
+// Wave priority of the detection chain's kernels (detect_nms, emit_features, bin_scan, bin_sort): their instructions
+// issue ahead of the searches' on a shared SIMD.  The chain is the step's critical path (4 sub-batches x 4 dependent
+// kernels, each slowed 2-3x by the searches beside it) while the searches only need their sum of issue slots.
+// MI355X, KITTI, S = 256, k pairs/s: priority 0 / 1 / 2 / 3 = 104.8 / 107.2 / 107.3 / 107.2 (round 5, after the
+// searches lost 6 % of their instructions; in round 3, with the heavier searches, the same switch was +-0).
+#ifndef VH_DET_PRIO
+#define VH_DET_PRIO 1
+#endif
+#define VH_DET_SETPRIO() do { if (VH_DET_PRIO) __builtin_amdgcn_s_setprio(VH_DET_PRIO); } while (0)
 // 32-bit match keys SAD << 19 | (bin-order position - first position of the class) serve classes
 // of up to 2^19 - 64 features per set (the staged chunks of the searches repeat the last candidate
 // of a run under positions up to 63 past it); larger classes take 64-bit keys (kernels_match.hip).

@@ -169,7 +169,9 @@ int32_t vh_remove_outliers_pm(vh_p_match *pm, int32_t n, int32_t *n_out);
  * (src/matcher.cpp:140-187), out receives the bucketed lists.  out_counts[l]: records of list l in out;
  * n_triangles (nullable): triangles of each list's triangulation; sweep_ms (nullable): device time of the
  * sweep kernel.  VH_ERR_CAPACITY if a list does not fit out_cap; VH_ERR_UNSUPPORTED for lists the sweep
- * refuses (NaN / infinite / negative coordinates, more than 257 flips pending). */
+ * refuses (NaN / infinite / negative coordinates, more than 31 flips pending in one legalisation -- the reference's
+ * stack has 13 slots and is undefined beyond; such a list's sweep stops at the flip that does not fit, nothing of it is
+ * delivered, out_counts[l] = 0, and the other lists of the call are delivered as usual). */
 int32_t vh_remove_outliers_device(int32_t device, int32_t n_lists, const vh_p_match *pm, int64_t stride, const int32_t *counts,
                                   int32_t lanes_per_wave, int32_t max_features, float bucket_width, float bucket_height,
                                   vh_p_match *out, int32_t out_cap, int32_t *out_counts, int32_t *n_triangles, float *sweep_ms);
@@ -441,6 +443,10 @@ int32_t vh_group_search_stats(vh_group *g, int32_t *speculative, double *researc
 /* Test hook: the next device allocation the group makes fails (VH_ERR_HIP), once.  Lets the suite drive the error
  * paths of lazily allocated buffers (the flow method's pixel mask). */
 int32_t vh_group_debug_fail_next_alloc(vh_group *g);
+/* Test hook: flip-stack entries the device vote's sweep may hold per list (1..31; 0 restores the default, 31), process-wide.
+ * With a small value ordinary match lists take the refusal path (VH_ERR_UNSUPPORTED for that list, see
+ * vh_remove_outliers_device). */
+int32_t vh_debug_vote_stack_slots(int32_t slots);
 /* Kernel timing (HIP events recorded on the group's stream around every
  * kernel launch while enabled).  vh_group_profile_read returns the
  * accumulated milliseconds and launch count of kernel `name`

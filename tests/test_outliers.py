@@ -355,6 +355,59 @@ def test_device_vote_equals_the_reference_fixtures_and_the_oracle(lanes, pkg, or
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [1, 16])
+def test_device_vote_kitti_size_known_answer(lanes, pkg, ob, oracle, gpu):
+    """The KITTI-size vector the REFERENCE's removeOutliers produced (tests/golden/outliers.npz: kitti__n_out /
+    kitti__fnv_out, src/remove_outliers.cpp:4-94 over src/delaunator.cpp:183-407): reference flow matches of the
+    Appendix-B frame pair with a tenth of the flows disturbed, through the DEVICE vote -- alone and as one of several
+    lists of a wave.  (Round 4 checked only the oracle and the host form against it.)"""
+    z = golden()
+    p = ob.Params.default()
+    dims = [1241, 376, 1248]
+    _, m2p = oracle.compute_features(p, pkg.synth.frame(1241, 376, 0, 0), dims)
+    _, m2c = oracle.compute_features(p, pkg.synth.frame(1241, 376, 5, 1), dims)
+    pm = oracle.matching(p, dims, 0, m1p=m2p, m1c=m2c)
+    pm["u1p"][z["kitti__disturbed"]] += z["kitti__du"].astype(np.float32)
+    rng = np.random.default_rng(31)
+    lists = [pm] + [random_matches(pkg, rng, n) for n in ((700, 2500) if lanes > 1 else ())]
+    got, ntri, _ = pkg.remove_outliers_device(lists, lanes_per_wave=lanes)
+    assert len(got[0]) == int(z["kitti__n_out"]) and pkg.synth.fnv1a64(got[0]) == int(z["kitti__fnv_out"])
+    assert ntri[0] > 17000
+    for g, l in zip(got[1:], lists[1:]):
+        assert g.tobytes() == oracle.remove_outliers(l)[0].tobytes()
+
+
+@pytest.mark.gpu
+def test_device_vote_flip_stack_exhausted_list_is_refused_alone(pkg, oracle, gpu):
+    """A list whose legalisation needs more pending flips than the sweep's stack holds is refused -- VH_ERR_UNSUPPORTED,
+    nothing of it delivered -- while the other lists of the same batch (and of the same WAVE) are delivered and equal the
+    oracle.  The sweep stops at the flip that does not fit: nothing is popped or written once an entry is lost
+    (csrc/sweep_hull.h: legalize / insert_all).  Driven with ordinary lists through the test hook that shrinks the stack."""
+    rng = np.random.default_rng(41)
+    lists = [random_matches(pkg, rng, n) for n in (2000, 6, 1500, 5, 900)]
+    want = [oracle.remove_outliers(l)[0] for l in lists]
+    depth = [oracle.remove_outliers(l)[1] for l in lists]
+    assert max(depth) >= 3 and depth[1] <= 2 and depth[3] <= 2  # (the long lists need a deeper stack than the tiny ones)
+    lib = pkg._lib()
+    try:
+        assert lib.vh_debug_vote_stack_slots(2) == 0
+        for lanes in (1, 64):
+            got, _, _, rc = pkg.remove_outliers_device(lists, lanes_per_wave=lanes, strict=False)
+            assert rc == pkg.VH_ERR_UNSUPPORTED
+            for k, (g, w) in enumerate(zip(got, want)):
+                if depth[k] <= 2:
+                    assert g.tobytes() == w.tobytes(), k
+                else:
+                    assert len(g) == 0, k
+    finally:
+        assert lib.vh_debug_vote_stack_slots(0) == 0
+    got, _, _ = pkg.remove_outliers_device(lists, lanes_per_wave=64)  # and with the shipped stack everything is delivered
+    for g, w in zip(got, want):
+        assert g.tobytes() == w.tobytes()
+    assert lib.vh_debug_vote_stack_slots(99) == pkg.VH_ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
 def test_device_vote_beyond_the_lds_tally(pkg, oracle, gpu):
     """Lists of more than 16 384 records (beyond the reference's own POINT_L = 14002 arrays, and beyond the per-list
     vote counters the tally keeps in LDS): the thread-per-triangle tally with global counters."""

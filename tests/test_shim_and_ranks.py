@@ -87,6 +87,25 @@ def test_two_rank_launch_gloo(pkg):
     assert r["value"] == pytest.approx(2 * 3 * 7 / (r["ms_per_step"] * 7e-3))  # whole-job aggregate over the MAX-reduced clock
 
 
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python3 bench.py --gpus 2 ...` from a clean environment (no RANK / WORLD_SIZE: not under a launcher) starts
+    torch.distributed.run itself as a child process, relays exactly ONE JSON line -- rank 0's -- and returns the
+    child's exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-selftest", "--streams", "3", "--steps", "4",
+                        "--warmup", "1", "--blocks", "3"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = r.stdout.decode().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout.decode()
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and sorted(x["rank"] for x in d["ranks_seen"]) == [0, 1]
+    assert d["global_stream_ids"] == [0, 1, 2, 3, 4, 5]
+    # a failing child is reported through the exit code (here: an argument the ranks reject)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-selftest", "--steps", "x"],
+                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert bad.returncode != 0 and not bad.stdout.decode().strip()
+
+
 def test_rank_protocol_single_process():
     """The same protocol object with one rank and no process group (what `python bench.py` uses at N = 1)."""
     sys.path.insert(0, ROOT)

@@ -11,7 +11,7 @@ for spec in "$@"; do
   lib=hls-final-visual-odometry_amd/libviso_hip.so
   [ "$v" != "-" ] && lib=hls-final-visual-odometry_amd/libviso_hip_$v.so
   out=gpurun_out/ab_${i}_${v}.json
-  VISO_HIP_LIB=$PWD/$lib python bench.py --no-cpu "$@" > $out 2> ${out%.json}.err || { echo "$spec: FAILED"; tail -3 ${out%.json}.err; continue; }
+  VISO_HIP_LIB=$PWD/$lib python bench.py --no-cpu --no-other "$@" > $out 2> ${out%.json}.err || { echo "$spec: FAILED"; tail -3 ${out%.json}.err; continue; }
   python - "$out" "$spec" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

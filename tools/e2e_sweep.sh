@@ -7,7 +7,7 @@ for spec in "$@"; do
   i=$((i+1))
   set -- $spec
   out=gpurun_out/e2e_${i}.json
-  VH_VOTE_PRIO=${4:-0} timeout -k 10 240 python bench.py --no-cpu --no-exclusive --no-e2e-host --e2e-steps-per-batch $1 --e2e-batches $2 --e2e-lanes $3 ${5:+--e2e-steps $5} > $out 2> ${out%.json}.err || { echo "$spec: FAILED"; tail -3 ${out%.json}.err; continue; }
+  VH_VOTE_PRIO=${4:-0} timeout -k 10 240 python bench.py --no-cpu --no-other --no-exclusive --no-e2e-host --e2e-steps-per-batch $1 --e2e-batches $2 --e2e-lanes $3 ${5:+--e2e-steps $5} > $out 2> ${out%.json}.err || { echo "$spec: FAILED"; tail -3 ${out%.json}.err; continue; }
   python - "$out" "$spec" <<'PY'
 import json, sys
 s = open(sys.argv[1]).read()

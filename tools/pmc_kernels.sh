@@ -15,6 +15,6 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
            "SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM" \
            "SQ_BUSY_CU_CYCLES SQ_WAVES SQ_LEVEL_WAVES SQ_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python bench.py --no-cpu --no-exclusive --no-e2e --no-flow --streams 128 --steps 4 --warmup 2 --blocks 1 > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python bench.py --no-cpu --no-other --no-exclusive --no-e2e --no-flow --streams 128 --steps 4 --warmup 2 --blocks 1 > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
   echo "pass $i ok: $set"
 done

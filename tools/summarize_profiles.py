@@ -72,10 +72,16 @@ for k, v in per.items():
 json.dump(out, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
 dom = bench["roofline"]["kernel"]
-import hashlib
-lib = os.path.join(ROOT, "hls-final-visual-odometry_amd", "libviso_hip.so")
-json.dump({"tag": tag, "streams": S, "kernel": dom, "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "hbm_bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"],
-           "per_kernel": {k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items()}},
+# what bench.py reads: tagged with a hash of the SOURCES that determine the code object (the driver rebuilds the
+# library, and every rebuild of the .so hashes differently: round 4's line lost its traffic to that)
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+json.dump({"tag": tag, "streams": S, "kernel": dom, "src_sha256": entry.load_package().source_sha256(),
+           "hbm_bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"],
+           "per_kernel": {k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items()},
+           "per_kernel_raw": {k: v["hbm_bytes_per_launch_raw"] for k, v in out["kernels"].items()},
+           "note": "bytes per LAUNCH from rocprofv3 FETCH_SIZE / WRITE_SIZE (separate passes); per_kernel = 2 x FETCH + WRITE "
+                   "(the guide's gfx950 correction for wide reads: an upper estimate here), per_kernel_raw = FETCH + WRITE"},
           open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print("value", bench["value"], "dominant", dom, "us(events)", bench["roofline"]["us_per_launch"], "us(rocprof)", avg_us.get(dom))
 for k, v in sorted(out["kernels"].items(), key=lambda kv: -(kv[1]["avg_us_rocprof_stats"] or 0)):

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/vtrace
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/vtrace -- python3 $R/bench.py --no-cpu --no-exclusive --no-e2e-host --steps 5 --warmup 2 --blocks 1 --e2e-steps-per-batch $1 --e2e-batches $2 --e2e-lanes $3 --e2e-steps ${4:-48} > $R/gpurun_out/vtrace.json 2> $R/gpurun_out/vtrace.err
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/vtrace -- python3 $R/bench.py --no-cpu --no-other --no-exclusive --no-e2e-host --steps 5 --warmup 2 --blocks 1 --e2e-steps-per-batch $1 --e2e-batches $2 --e2e-lanes $3 --e2e-steps ${4:-48} > $R/gpurun_out/vtrace.json 2> $R/gpurun_out/vtrace.err
 python3 - <<'PY'
 import csv, glob, os
 R = os.environ["GRAFT_REPO_ROOT"]
