@@ -510,8 +510,9 @@ class StreamGroup:
         lists = [out[s, :counts[s]].copy() for s in range(S)] if want_lists else None
         return {"tr": tr, "ok": ok.astype(bool), "n_inliers": ninl, "lists": lists, "counts": counts, "host_ms": ms.value}
 
-    def postDeviceConfig(self, steps_per_batch: int = 4, batches: int = 4, lanes_per_wave: int = 1):
-        """Shape of the device post stage's pipeline (vh_group_post_device_config)."""
+    def postDeviceConfig(self, steps_per_batch: int = 64, batches: int = 3, lanes_per_wave: int = 16):
+        """Shape of the device post stage's pipeline (vh_group_post_device_config); the defaults are the library's own
+        (64 steps per batch, 3 batches, 16 lists per wave: the throughput-optimal shape, up to a second of latency)."""
         _check(_lib().vh_group_post_device_config(self._h, int(steps_per_batch), int(batches), int(lanes_per_wave)), "vh_group_post_device_config")
 
     def postBeginDevice(self, cap_per_stream: int, max_features: int, bucket_width: float, bucket_height: float,
@@ -530,16 +531,18 @@ class StreamGroup:
                                                  C.byref(mono) if mono is not None else None, _ptr(r8), 1 if want_lists else 0),
                "vh_group_post_begin_device")
 
-    def postFinishDevice(self, age: int, want_lists: bool = False, list_cap: int = 4096, estimator: bool = True):
-        """Results of the step begun `age` begins ago (vh_group_post_finish_device) -> dict(tr, ok, n_inliers, lists, counts)."""
+    def postFinishDevice(self, age: int, want_lists: bool = False, list_cap: int = 4096, estimator: bool = True, strict: bool = True):
+        """Results of the step begun `age` begins ago (vh_group_post_finish_device) -> dict(tr, ok, n_inliers, lists, counts).
+        strict=False: a refused list does not raise; its stream reports counts = -1 and the dict carries the code as "rc"."""
         S = self.S
         tr = np.zeros((S, 6), np.float64); ok = np.zeros(S, np.int32); ninl = np.zeros(S, np.int32); counts = np.zeros(S, np.int32)
         out = np.zeros((S, int(list_cap)), P_MATCH_DTYPE) if want_lists else None
-        _check(_lib().vh_group_post_finish_device(self._h, int(age), _ptr(tr) if estimator else None, _ptr(ok) if estimator else None,
-                                                  _ptr(ninl) if estimator else None, _ptr(out), int(list_cap) if want_lists else 0, _ptr(counts)),
-               "vh_group_post_finish_device")
-        lists = [out[s, :counts[s]].copy() for s in range(S)] if want_lists else None
-        return {"tr": tr, "ok": ok.astype(bool), "n_inliers": ninl, "lists": lists, "counts": counts}
+        rc = _lib().vh_group_post_finish_device(self._h, int(age), _ptr(tr) if estimator else None, _ptr(ok) if estimator else None,
+                                                _ptr(ninl) if estimator else None, _ptr(out), int(list_cap) if want_lists else 0, _ptr(counts))
+        if strict or rc in (VH_ERR_INVALID_ARG, VH_ERR_STATE, VH_ERR_HIP, VH_ERR_NO_DEVICE):
+            _check(rc, "vh_group_post_finish_device")
+        lists = [out[s, :max(int(counts[s]), 0)].copy() for s in range(S)] if want_lists else None
+        return {"tr": tr, "ok": ok.astype(bool), "n_inliers": ninl, "lists": lists, "counts": counts, "rc": rc}
 
     def estimateMotionMono(self, mono: "MonoParams", rand8):
         """VisualOdometryMono::estimateMotion (reference src/viso_mono.cpp:41-160) on every stream's device-resident

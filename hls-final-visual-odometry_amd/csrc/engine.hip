@@ -111,7 +111,6 @@ struct Group {
   int32_t dims[3] = {0, 0, 0};
   VhGeom g{};
   VhSets sets{};
-  VhOrder order{};  // bin-ordered emission (vh_dev.h); order.enabled == 0: staging + bin_sort
   int32_t cap = 0, mcap = 0;
   int32_t pair_cur = 0;
   int64_t frames = 0;
@@ -204,7 +203,7 @@ struct Group {
     device_bytes = 0;
     d_stage[0] = d_stage[1] = nullptr; stage_bytes = 0; ev_down_valid = false;
     for (int k = 0; k < 2; k++) d_stage_buf[k][0] = d_stage_buf[k][1] = nullptr, ev_stage_valid[k] = false;
-    d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr; order = VhOrder{}; d_prior_tr = nullptr;
+    d_half = nullptr; d_rec = nullptr; d_chunk_count = nullptr; d_best = nullptr; d_chain = nullptr; d_prior_tr = nullptr;
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk2[0] = d_mchunk2[1] = nullptr; d_redo = nullptr;
     for (int k = 0; k < 2; k++) if (h_out[k]) { (void)hipHostFree(h_out[k]); h_out[k] = nullptr; d_out_mapped[k] = nullptr; }
     if (h_matches) { (void)hipHostFree(h_matches); h_matches = nullptr; d_matches_mapped = nullptr; }
@@ -287,63 +286,6 @@ struct Group {
     return VH_ERR_UNSUPPORTED;
   }
 
-  // Geometry of the bin-ordered emission (VhOrder): which v-bins and pixel rows each chunk of VH_CHUNK NMS blocks can
-  // touch, and -- the other way round -- which chunks can hold members of a v-bin / a pixel row.  Possible when a
-  // chunk's counters fit the kernels' LDS tables; VH_ORDER=1 selects it (the suite runs on both paths).
-  int32_t setup_order() {
-    order = VhOrder{};
-    // Default OFF, on measurement (profiles/EXPERIMENTS.md, round 4): bit-exact and 6 % less exclusive kernel time in the
-    // detection chain (no bin_sort, no staging, no per-feature atomic), but its two extra latency-bound launches
-    // (count_chunks, a heavier scan) make the overlapped step 1 % SLOWER at KITTI size (99.7-100.9 k vs 100.5-101.8 k pairs/s).
-    static const bool on = [] { const char *e = getenv("VH_ORDER"); return e && e[0] == '1'; }();
-    if (!on || g.nblocks <= 0 || sets.ubn < 1 || sets.vbn < 1) return VH_OK;
-    const int32_t n1 = g.n + 1, nch = g.nchunks, H = dims[1];
-    std::vector<int32_t> vbf(nch), vf(nch), vbl(nch), vl(nch);
-    int32_t VB = 1, VROW = 1;
-    for (int32_t k = 0; k < nch; k++) {
-      const int32_t b0 = k * VH_CHUNK, b1 = std::min(b0 + VH_CHUNK, g.nblocks) - 1;
-      vf[k] = ((b0 / g.nbx) * n1 + g.n + VH_MARGIN) * g.scale;             // smallest v of a feature of the chunk (full resolution)
-      vl[k] = ((b1 / g.nbx) * n1 + g.n + VH_MARGIN + g.n) * g.scale;       // largest
-      vbf[k] = std::min(vf[k] / sets.binsize, sets.vbn - 1);
-      vbl[k] = std::min(vl[k] / sets.binsize, sets.vbn - 1);
-      VB = std::max(VB, vbl[k] - vbf[k] + 1);
-      VROW = std::max(VROW, vl[k] - vf[k] + 1);
-    }
-    const int64_t nslot = 4 * (int64_t)sets.ubn * VB;
-    if (nslot > VH_ORDER_SLOTS_MAX || VROW > VH_ORDER_ROWS_MAX) return VH_OK;
-    std::vector<int32_t> bk0(sets.vbn, 1), bk1(sets.vbn, 0), rk0(H, 1), rk1(H, 0);
-    for (int32_t k = nch - 1; k >= 0; k--) {
-      for (int32_t vb = vbf[k]; vb <= vbl[k]; vb++) bk0[vb] = k;
-      for (int32_t v = vf[k]; v <= std::min(vl[k], H - 1); v++) rk0[v] = k;
-    }
-    for (int32_t k = 0; k < nch; k++) {
-      for (int32_t vb = vbf[k]; vb <= vbl[k]; vb++) bk1[vb] = k;
-      for (int32_t v = vf[k]; v <= std::min(vl[k], H - 1); v++) rk1[v] = k;
-    }
-    int32_t rc;
-    int32_t *d_tab = nullptr;
-    const size_t ntab = 2 * (size_t)nch + 2 * (size_t)sets.vbn + 2 * (size_t)H;
-    if ((rc = dmalloc(&d_tab, ntab, false))) return rc;
-    std::vector<int32_t> tab;
-    tab.insert(tab.end(), vbf.begin(), vbf.end()); tab.insert(tab.end(), vf.begin(), vf.end());
-    tab.insert(tab.end(), bk0.begin(), bk0.end()); tab.insert(tab.end(), bk1.begin(), bk1.end());
-    tab.insert(tab.end(), rk0.begin(), rk0.end()); tab.insert(tab.end(), rk1.begin(), rk1.end());
-    VH_HIP(hipMemcpy(d_tab, tab.data(), sizeof(int32_t) * ntab, hipMemcpyHostToDevice));
-    order.vb_first = d_tab; order.v_first = d_tab + nch;
-    order.bin_k0 = d_tab + 2 * nch; order.bin_k1 = order.bin_k0 + sets.vbn;
-    order.row_k0 = order.bin_k1 + sets.vbn; order.row_k1 = order.row_k0 + H;
-    order.VB = VB; order.VROW = VROW; order.nslot = (int32_t)nslot;
-    order.slot_bits = 1;
-    while ((1 << order.slot_bits) < order.nslot) order.slot_bits++;
-    const size_t nimg = 2 * (size_t)S;
-    if ((rc = dmalloc(&order.cbin, nimg * nch * (size_t)nslot, false))) return rc;
-    if ((rc = dmalloc(&order.crow, nimg * nch * 4 * (size_t)VROW, false))) return rc;
-    if ((rc = dmalloc(&order.cbase, nimg * ((size_t)nch + 1), true))) return rc;
-    if ((rc = dmalloc(&order.pos_of, 2 * VH_RING * (size_t)S * cap, false))) return rc;
-    order.enabled = 1;
-    return VH_OK;
-  }
-
   int32_t ensure(const int32_t d[3]) {
     if (allocated && d[0] == dims[0] && d[1] == dims[1] && d[2] == dims[2]) return VH_OK;
     if (allocated) { int32_t rs = sync_all(); if (rs) return rs; release(); }
@@ -367,14 +309,13 @@ struct Group {
     sets.ubn = (dims[0] + p.match_binsize - 1) / p.match_binsize;  // ceil(W/binsize), matcher.cpp:282-283
     sets.vbn = (dims[1] + p.match_binsize - 1) / p.match_binsize;
     sets.nbins = 4 * sets.ubn * sets.vbn;
-    sets.max_tiles = cap / VH_TILE_Q + 4 * sets.ubn + 1;  // full tiles + one partial tile per tile group
+    sets.max_tiles = cap / VH_TILE_Q + 5;  // full tiles + one partial tile per class
     sets.W = dims[0]; sets.H = dims[1];
     {  // a bin of binsize px meets at most ceil(binsize/block)+1 NMS blocks per axis, one feature per class each
       const int32_t blk = g.scale * (g.n + 1);
       const int64_t per_axis = (p.match_binsize + blk - 1) / blk + 1;
       sets.stage_cap = (int32_t)std::min<int64_t>(per_axis * per_axis, cap);
     }
-    sets.tile_span = (2 * p.match_radius >= dims[1]) ? sets.ubn * sets.vbn : sets.vbn;
     const size_t ns = 2 * VH_RING * (size_t)S;  // ring slots x (left, right) per stream
     if ((rc = dmalloc(&sets.feat, ns * cap * 12, false))) return rc;
     if ((rc = dmalloc(&sets.f_uv, ns * cap, false))) return rc;
@@ -385,9 +326,7 @@ struct Group {
     if ((rc = dmalloc(&sets.hist, ns * sets.nbins, true))) return rc;
     if ((rc = dmalloc(&sets.cursor, ns * sets.nbins, true))) return rc;
     if ((rc = dmalloc(&sets.tmp_idx, ns * cap, false))) return rc;
-    if ((rc = setup_order())) return rc;
-    // (the per-bin staging lists are only needed when the features are not emitted in bin order: 2 MB per set at KITTI size)
-    if (!order.enabled && (rc = dmalloc(&sets.stage, ns * (size_t)sets.nbins * sets.stage_cap, false))) return rc;
+    if ((rc = dmalloc(&sets.stage, ns * (size_t)sets.nbins * sets.stage_cap, false))) return rc;  // (per-bin staging lists: 2 MB per set at KITTI size)
     if ((rc = dmalloc(&sets.count, ns, true))) return rc;
     const size_t nrow = 4 * (size_t)dims[1];
     if ((rc = dmalloc(&sets.row_start, ns * (nrow + 1), true))) return rc;
@@ -456,9 +395,9 @@ struct Group {
   }
 
   // ---- detect + bin ------------------------------------------------------
-  int32_t zero_bin_counters(int32_t set0, int32_t nsets, int32_t *extra = nullptr, int64_t n_extra = 0, bool light = false) {
+  int32_t zero_bin_counters(int32_t set0, int32_t nsets, int32_t *extra = nullptr, int64_t n_extra = 0) {
     // one launch instead of a memset per array
-    vh_launch_zero_counters(sets, set0, nsets, extra, n_extra, light ? 1 : 0, stream);
+    vh_launch_zero_counters(sets, set0, nsets, extra, n_extra, stream);
     VH_HIP(hipGetLastError());
     return VH_OK;
   }
@@ -506,7 +445,7 @@ struct Group {
       VH_HIP(hipStreamWaitEvent(stream, ev_user, 0));
     }
     if (ev_read_valid[pair_cur]) VH_HIP(hipStreamWaitEvent(stream, ev_read[pair_cur], 0));
-    if ((rc = zero_bin_counters(set0, nsets, d_chunk_count, 2 * (int64_t)S * g.nchunks, order.enabled != 0))) return rc;
+    if ((rc = zero_bin_counters(set0, nsets, d_chunk_count, 2 * (int64_t)S * g.nchunks))) return rc;
     // The group is detected in up to four sub-batches of streams, one after the other on this
     // stream: the latency-bound kernels of a sub-batch (emit_features, bin_scan, bin_sort: < 45 %
     // of the VALU issue slots) then run beside the issue-bound ones of its neighbours and of the
@@ -539,20 +478,9 @@ struct Group {
         im.base[0] = half; im.base[1] = half + isz; im.stride = isz * ncam;
       }
       { Scope sc(this, "detect_nms", stream); vh_launch_detect_nms(im, g, rec, chunks, stream); }
-      if (order.enabled) {
-        // counts per chunk -> scan -> emission straight into bin order (no staging, no sort, no per-feature atomic)
-        VhOrder o = order;
-        const size_t i0 = (size_t)s0 * ncam;
-        o.cbin += i0 * g.nchunks * (size_t)o.nslot; o.crow += i0 * g.nchunks * 4 * (size_t)o.VROW; o.cbase += i0 * ((size_t)g.nchunks + 1);
-        { Scope sc(this, "count_chunks", stream); vh_launch_count_chunks(im, g, rec, sets, o, stream); }
-        { Scope sc(this, "bin_scan", stream); vh_launch_bin_scan_ordered(im, g, chunks, sets, o, set0 + 2 * s0, 2 * sn, stream); }
-        { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, rec, chunks, sets, o, stream); }
-        VH_HIP(hipGetLastError());
-      } else {
-        { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, rec, chunks, sets, order, stream); }
-        VH_HIP(hipGetLastError());
-        if ((rc = bin_sets(set0 + 2 * s0, 2 * sn, true))) return rc;
-      }
+      { Scope sc(this, "emit_features", stream); vh_launch_emit_features(im, g, rec, chunks, sets, stream); }
+      VH_HIP(hipGetLastError());
+      if ((rc = bin_sets(set0 + 2 * s0, 2 * sn, true))) return rc;
     }
     VH_HIP(hipEventRecord(ev_det[pair_cur], stream));
     return VH_OK;
@@ -1214,8 +1142,27 @@ struct Group {
     int32_t rc = bucket_need(max_features, bw, bh, &need, &grid);
     if (rc) return rc;
     cap_ps = std::min(cap_ps, mcap);
-    if (cap_ps > 65536) return VH_ERR_UNSUPPORTED;  // (the sweep's angular hash has VH_VOTE_HASH_MAX slots in LDS)
+    if (cap_ps > VH_VOTE_LIST_MAX) return VH_ERR_UNSUPPORTED;  // (16-bit hull links; the sweep's angular hash has VH_VOTE_HASH_MAX slots in LDS)
     if (vbatch.empty()) {
+      // The ring is allocated batch by batch on first use: it must fit the device NOW, or a later begin call -- with steps
+      // already moved -- fails in hipMalloc.  Steps per batch are halved until vote_batches batches fit 80 % of the free
+      // memory; if a single step per batch does not fit, nothing has moved yet and the caller is told so.
+      size_t free_b = 0, total_b = 0;
+      VH_HIP(hipMemGetInfo(&free_b, &total_b));
+      const auto ring_bytes = [&](int32_t steps) {
+        const int32_t P = steps * S;
+        const size_t post = (e ? sizeof(double) * 4 * (size_t)P * (size_t)need : 0) + (mono ? (size_t)vh_mono_scratch_bytes(P, (int32_t)need, mono->ransac_iters) : 0) +
+                            sizeof(double) * 6 * (size_t)P + sizeof(int32_t) * 2 * (size_t)P +
+                            sizeof(int32_t) * (size_t)steps * (e ? (size_t)S * e->ransac_iters * 3 : (mono ? (size_t)S * mono->ransac_iters * 8 : 0));
+        return (double)vote_batches * (double)(VhVoteBuffers::bytes_for(P, cap_ps, (int32_t)need, (int32_t)grid) + post);
+      };
+      int32_t steps = vote_steps;
+      while (steps > 1 && ring_bytes(steps) > 0.8 * (double)free_b) steps = (steps + 1) / 2;
+      if (ring_bytes(steps) > 0.8 * (double)free_b) {
+        t_last_error = "the post stage's ring of batches does not fit the device's free memory even at one step per batch";
+        return VH_ERR_CAPACITY;
+      }
+      vote_steps = steps;
       vbatch.resize((size_t)vote_batches);
       vstep.assign((size_t)vote_steps * vote_batches, VoteStep{});
       int prio_lo = 0, prio_hi = 0;
@@ -1253,6 +1200,12 @@ struct Group {
       b->steps = 0; b->launched = false; b->busy = false; b->handed = 0;
       const int32_t P = vote_steps * S;
       if (b->vb.v.cap < cap_ps || b->vb.out_cap < need || b->vb.v.P < P || b->vb.v.nb_max < grid) {
+        if (b->vb.block) {  // a batch grows (longer lists than the ring was sized for): only if the difference fits
+          size_t free_b = 0, total_b = 0;
+          VH_HIP(hipMemGetInfo(&free_b, &total_b));
+          const size_t want = VhVoteBuffers::bytes_for(P, cap_ps, (int32_t)need, (int32_t)grid);
+          if (want > b->vb.bytes && want - b->vb.bytes > free_b) { t_last_error = "the post stage's batch cannot grow: device memory exhausted"; return VH_ERR_CAPACITY; }
+        }
         b->vb.release();
         VH_HIP(b->vb.alloc(P, cap_ps, (int32_t)need, (int32_t)grid));
         VH_HIP(b->vb.upload_lfsr());
@@ -1330,29 +1283,34 @@ struct Group {
     b.handed++;
     if (b.handed >= b.steps) b.busy = false;
     const size_t p0 = (size_t)st.pos * S, P = (size_t)b.steps * S;
-    int32_t ret = VH_OK;
-    for (int32_t s = 0; s < S; s++) {
-      const VhVoteMeta &m = b.h_meta[p0 + s];
-      if (m.status == VH_VOTE_TRUNCATED) ret = VH_ERR_CAPACITY;
-      else if (m.status != VH_VOTE_OK && m.status != VH_VOTE_SKIP && ret == VH_OK) ret = VH_ERR_UNSUPPORTED;
-    }
-    if (ret) return ret;
     if ((b.has_ego || b.has_mono) && (!tr || !ok || !ninl)) return VH_ERR_INVALID_ARG;
+    if (out && !b.want_lists) return VH_ERR_STATE;
     if (b.has_ego || b.has_mono) {
       memcpy(tr, b.h_tr + 6 * p0, sizeof(double) * 6 * (size_t)S);
       memcpy(ok, b.h_ok + p0, sizeof(int32_t) * (size_t)S);
       memcpy(ninl, b.h_ok + P + p0, sizeof(int32_t) * (size_t)S);
     }
     if (out_counts) memcpy(out_counts, b.h_cnt + p0, sizeof(int32_t) * (size_t)S);
-    if (out) {
-      if (!b.want_lists) return VH_ERR_STATE;
-      for (int32_t s = 0; s < S; s++) {
+    // One refused list does not void the step: the healthy streams are delivered, a refused stream reports
+    // ok = 0, n_inliers = 0, tr = 0, counts = -1, and the call returns the error (capacity before unsupported).
+    int32_t ret = VH_OK;
+    for (int32_t s = 0; s < S; s++) {
+      const VhVoteMeta &m = b.h_meta[p0 + s];
+      const bool bad = m.status != VH_VOTE_OK && m.status != VH_VOTE_SKIP;
+      if (m.status == VH_VOTE_TRUNCATED) ret = VH_ERR_CAPACITY;
+      else if (bad && ret == VH_OK) ret = VH_ERR_UNSUPPORTED;
+      if (bad) {
+        if (b.has_ego || b.has_mono) { for (int k = 0; k < 6; k++) tr[6 * (size_t)s + k] = 0.0; ok[s] = 0; ninl[s] = 0; }
+        if (out_counts) out_counts[s] = -1;
+        continue;
+      }
+      if (out) {
         const int32_t k = b.h_cnt[p0 + s];
-        if (k > out_cap) return VH_ERR_CAPACITY;
+        if (k > out_cap) { ret = VH_ERR_CAPACITY; if (out_counts) out_counts[s] = -1; continue; }
         memcpy(out + (size_t)s * out_cap, b.h_out + (p0 + s) * (size_t)b.vb.out_cap, sizeof(vh_p_match) * (size_t)k);
       }
     }
-    return VH_OK;
+    return ret;
   }
 
   // Load caller-supplied feature records into a role's set and index it.
@@ -1566,7 +1524,13 @@ void vh_group_destroy(vh_group *g) {
   delete gq;
 }
 int32_t vh_group_streams(const vh_group *g) { return g ? ((const Group *)g)->S : VH_ERR_INVALID_ARG; }
-int64_t vh_group_device_bytes(const vh_group *g) { return g ? ((const Group *)g)->device_bytes : (int64_t)VH_ERR_INVALID_ARG; }
+int64_t vh_group_device_bytes(const vh_group *g) {  // (the matcher's arrays and, once begun, the post stage's ring of batches)
+  if (!g) return (int64_t)VH_ERR_INVALID_ARG;
+  const Group *gq = (const Group *)g;
+  int64_t b = (int64_t)gq->device_bytes;
+  for (const auto &vb : gq->vbatch) b += (int64_t)vb.vb.bytes + (int64_t)vb.block_bytes;
+  return b;
+}
 int32_t vh_group_push_back_device(vh_group *g, const void *dI1, const void *dI2, int64_t stride_bytes,
                                   const int32_t dims[3], int32_t replace) {
   Group *gq = (Group *)g; ENTER(gq);
@@ -2095,7 +2059,7 @@ int32_t vh_remove_outliers_device(int32_t device, int32_t n_lists, const vh_p_ma
     cap = std::max(cap, counts[l]);
   }
   if (cap > 1 && !pm) return VH_ERR_INVALID_ARG;
-  if (cap > 65536) return VH_ERR_UNSUPPORTED;  // (the sweep's angular hash has VH_VOTE_HASH_MAX slots in LDS)
+  if (cap > VH_VOTE_LIST_MAX) return VH_ERR_UNSUPPORTED;  // (16-bit hull links; the sweep's angular hash has VH_VOTE_HASH_MAX slots in LDS)
   const int32_t rc = select_device(device);
   if (rc) return rc;
   VhVoteBuffers vb;

@@ -36,9 +36,8 @@ __device__ __forceinline__ int32_t feature_bin(const int32_t *__restrict__ f, co
 
 // Zero every per-frame counter of sets [set0, set0+nsets) -- feature counts,
 // bin and row histograms and cursors -- plus an optional extra array, in one launch.
-// light: only the feature counts and the extra array (bin-ordered emission: no histogram is accumulated in place)
-__global__ void zero_counters_kernel(VhSets s, int32_t set0, int32_t nsets, int32_t *__restrict__ extra, int64_t n_extra, int32_t light) {
-  const int64_t nb = light ? 0 : (int64_t)nsets * s.nbins, nr = light ? 0 : (int64_t)nsets * 4 * s.H;
+__global__ void zero_counters_kernel(VhSets s, int32_t set0, int32_t nsets, int32_t *__restrict__ extra, int64_t n_extra) {
+  const int64_t nb = (int64_t)nsets * s.nbins, nr = (int64_t)nsets * 4 * s.H;
   const int64_t total = 2 * nb + 2 * nr + nsets + n_extra;
   int32_t *hist = s.hist + (int64_t)set0 * s.nbins, *cur = s.cursor + (int64_t)set0 * s.nbins;
   int32_t *rh = s.row_hist + (int64_t)set0 * 4 * s.H, *rc = s.row_cursor + (int64_t)set0 * 4 * s.H;
@@ -166,92 +165,6 @@ __global__ void __launch_bounds__(VH_SCAN_T) bin_scan_kernel(VhSets s, int32_t s
   if (tid == 0) rs[nrow] = nrowfeat;
 }
 
-// VhOrder: the scan BEFORE the emission.  One workgroup per set of the launch (stream-major, two cameras per
-// stream; a camera the push did not bring gets empty indices).  From the per-chunk counts (count_chunks):
-//   * cbase[k]: index of chunk k's first feature; chunks that do not fit the capacity as a whole stay out of the
-//     bin order (their records are still written in index order up to the capacity, and count[] says the truth);
-//   * bin_start, and in place of every (chunk, bin) count the offset of the chunk's first member inside its bin;
-//   * the query tiles; row_start and the (chunk, row) offsets likewise.
-// Sum of the counts a bin (or row) holds in chunks [k0, k1], each count replaced by the sum of the ones before it.
-// The counts are requested eight at a time before the first of them is used (as a loop of load -> store pairs the
-// stores keep every next load waiting: one round trip per chunk instead of one per eight).
-template <class Addr>
-__device__ __forceinline__ int32_t prefix_over_chunks(int32_t k0, int32_t k1, Addr addr) {
-  int32_t run = 0;
-  for (int32_t kb = k0; kb <= k1; kb += 8) {
-    int32_t *q[8];
-    int32_t cnt[8];
-#pragma unroll
-    for (int32_t t = 0; t < 8; t++) { q[t] = kb + t <= k1 ? addr(kb + t) : nullptr; cnt[t] = q[t] ? *q[t] : 0; }
-#pragma unroll
-    for (int32_t t = 0; t < 8; t++) { if (q[t]) *q[t] = run; run += cnt[t]; }
-  }
-  return run;
-}
-
-// part 0: chunks, bins, tiles; part 1: (class, v) rows -- two workgroups per set, side by side
-__global__ void __launch_bounds__(VH_SCAN_T) bin_scan_ordered_kernel(VhSets s, VhOrder o, const int32_t *__restrict__ chunk_count,
-                                                                    int32_t nchunks, int32_t ncam, int32_t set0) {
-  __shared__ int32_t sWave[VH_SCAN_T / 64];
-  __shared__ int32_t sDrop;
-  const int32_t j = blockIdx.x, part = blockIdx.y, set = set0 + j, tid = threadIdx.x;
-  const int32_t cam = j & 1;
-  const bool has = cam < ncam;
-  const int32_t id = (j >> 1) * ncam + cam;
-  if (tid == 0) sDrop = nchunks;
-  __syncthreads();
-  int32_t *__restrict__ cbase = o.cbase + (int64_t)id * (nchunks + 1);
-  int32_t total = 0;
-  if (has) {  // (workgroup-uniform)
-    const int32_t *__restrict__ cc = chunk_count + (int64_t)id * nchunks;
-    total = scan_exclusive<4>(nchunks, sWave, [&](int32_t k) { return cc[k]; },
-                              [&](int32_t k, int32_t prefix, int32_t v) {
-                                if (part == 0) cbase[k] = prefix;
-                                if (prefix + v > s.cap) atomicMin(&sDrop, k);
-                              });
-  }
-  __syncthreads();
-  const int32_t kdrop = has ? sDrop : 0;  // chunks [kdrop, nchunks) are not indexed
-  if (part == 1) {
-    // (class, v) rows
-    const int32_t nrow = 4 * s.H;
-    int32_t *__restrict__ rs = s.row_start + (int64_t)set * (nrow + 1);
-    int32_t *__restrict__ crow = o.crow + (int64_t)id * nchunks * 4 * o.VROW;
-    const int32_t nrowfeat = scan_exclusive<4>(
-        nrow, sWave,
-        [&](int32_t r) {
-          const int32_t c = r / s.H, v = r - c * s.H;
-          if (!has) return 0;
-          return prefix_over_chunks(o.row_k0[v], min(o.row_k1[v], kdrop - 1), [&](int32_t k) -> int32_t * {
-            const int32_t vrel = v - o.v_first[k];
-            return (vrel < 0 || vrel >= o.VROW) ? nullptr : crow + ((int64_t)k * 4 + c) * o.VROW + vrel;
-          });
-        },
-        [&](int32_t r, int32_t prefix, int32_t) { rs[r] = prefix; });
-    if (tid == 0) rs[nrow] = nrowfeat;
-    return;
-  }
-  if (tid == 0) { if (has) cbase[nchunks] = kdrop; s.count[set] = total; }
-
-  int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
-  int32_t *__restrict__ cbin = o.cbin + (int64_t)id * nchunks * o.nslot;
-  const int32_t nfeat = scan_exclusive<4>(
-      s.nbins, sWave,
-      [&](int32_t b) {
-        const int32_t vb = b % s.vbn, cu = b / s.vbn;
-        if (!has) return 0;
-        return prefix_over_chunks(o.bin_k0[vb], min(o.bin_k1[vb], kdrop - 1), [&](int32_t k) -> int32_t * {
-          const int32_t vrel = vb - o.vb_first[k];
-          return (vrel < 0 || vrel >= o.VB) ? nullptr : cbin + (int64_t)k * o.nslot + cu * o.VB + vrel;
-        });
-      },
-      [&](int32_t b, int32_t prefix, int32_t) { bs[b] = prefix; });
-  if (tid == 0) bs[s.nbins] = nfeat;
-  __syncthreads();  // bin_start is read back below by other lanes
-
-  make_tiles(s, bs, set);
-}
-
 __global__ void bin_fill_kernel(VhSets s, int32_t set0) {
   const int32_t set = set0 + blockIdx.y;
   const int32_t n = min(s.count[set], s.cap);
@@ -356,11 +269,10 @@ __global__ void ref_index_kernel(VhSets s, int32_t set, int32_t *__restrict__ bs
 // grid would be ~75 % empty workgroups at typical densities.
 static int32_t feature_blocks(const VhSets &s) { return std::min(std::max(s.cap / 1024, 8), 256); }
 
-void vh_launch_zero_counters(const VhSets &s, int32_t set0, int32_t nsets, int32_t *extra, int64_t n_extra, int32_t light,
-                             hipStream_t st) {
-  const int64_t total = (light ? 0 : 2 * (int64_t)nsets * s.nbins + 8 * (int64_t)nsets * s.H) + nsets + n_extra;
+void vh_launch_zero_counters(const VhSets &s, int32_t set0, int32_t nsets, int32_t *extra, int64_t n_extra, hipStream_t st) {
+  const int64_t total = 2 * (int64_t)nsets * s.nbins + 8 * (int64_t)nsets * s.H + nsets + n_extra;
   const int32_t blocks = (int32_t)std::min<int64_t>((total + 1023) / 1024, 2048);
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, s, set0, nsets, extra, n_extra, light);
+  hipLaunchKernelGGL(zero_counters_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, s, set0, nsets, extra, n_extra);
 }
 
 void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
@@ -369,10 +281,6 @@ void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_
 }
 void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
   hipLaunchKernelGGL(bin_scan_kernel, dim3(nsets), dim3(VH_SCAN_T), 0, st, s, set0);
-}
-void vh_launch_bin_scan_ordered(const VhImages &im, const VhGeom &g, const int32_t *chunk_count, const VhSets &s, const VhOrder &o,
-                                int32_t set0, int32_t nsets, hipStream_t st) {
-  hipLaunchKernelGGL(bin_scan_ordered_kernel, dim3(nsets, 2), dim3(VH_SCAN_T), 0, st, s, o, chunk_count, g.nchunks, im.ncam, set0);
 }
 void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st) {
   dim3 grid(feature_blocks(s), nsets);

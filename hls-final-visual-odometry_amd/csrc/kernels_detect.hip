@@ -605,18 +605,14 @@ __constant__ int8_t c_desc_dy[16] = {-1, +1, -1, +1, -1, +1, -1, +1, -5, +5, -5,
 #ifndef VH_EMIT_NF
 #define VH_EMIT_NF 2
 #endif
-// ORDERED (VhOrder, vh_dev.h): the chunk's features go straight to their final bin-order positions -- the scan has
-// run BEFORE this kernel and left, per (chunk, bin) and per (chunk, row), the offset of the chunk's first member.
-template <bool ORDERED>
 __global__ void __launch_bounds__(256)
 emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
-                     const int32_t *__restrict__ chunk_count, VhSets s, VhOrder o) {
+                     const int32_t *__restrict__ chunk_count, VhSets s) {
   int32_t *__restrict__ feat = s.feat;
   int32_t *__restrict__ count = s.count;
   const int32_t cap = s.cap;
   __shared__ uint32_t sList[4 * VH_CHUNK + 1];  // u | v<<14 | c<<28 (matching-resolution coords); last word = sink for empty slots
   __shared__ int32_t sWave[4], sWaveP[4];
-  extern __shared__ int32_t sSlot[];  // ORDERED: [o.nslot] members of the chunk's (class, u-bin, v-bin) slots ranked so far
 
   const int32_t id = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const uint8_t *__restrict__ I = vh_image_ptr(im, id);
@@ -639,10 +635,9 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
       clo[k] = c.x; chi[k] = c.y;
     }
   }
-  // features emitted by earlier chunks of this image (ORDERED: the scan has added them up already)
+  // features emitted by earlier chunks of this image
   int32_t part = 0;
-  if (ORDERED) part = tid == 0 ? o.cbase[(int64_t)id * (g.nchunks + 1) + chunk] : 0;
-  else for (int32_t k = tid; k < chunk; k += 256) part += chunk_count[(int64_t)id * g.nchunks + k];
+  for (int32_t k = tid; k < chunk; k += 256) part += chunk_count[(int64_t)id * g.nchunks + k];
   int32_t mine = 0;
 #pragma unroll
   for (int32_t k = 0; k < BPL; k++) {
@@ -684,7 +679,7 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     }
   }
   __syncthreads();
-  if (!ORDERED && chunk == g.nchunks - 1 && tid == 0) count[set] = base + total;  // (ORDERED: written by the scan)
+  if (chunk == g.nchunks - 1 && tid == 0) count[set] = base + total;
   VH_ETICK(1);
   // (phase B's lane roles, here because its first patch loads are requested now, ahead of phase A2)
   const int32_t grp = tid >> 4, k = tid & 15;
@@ -694,32 +689,22 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   // The patch rows of trip i+1 are in flight while trip i is handed round, computed and stored
   // (one 16-byte load per lane and feature: 8 registers for the double buffer).
   typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
-  struct Coords { int32_t fs[NF], us[NF], vs[NF], cs[NF], ps[NF]; bool lives[NF]; };
-  // ORDERED: a chunk whose features do not all fit the capacity stays out of the bin order altogether
-  const bool dropped = ORDERED && chunk >= o.cbase[(int64_t)id * (g.nchunks + 1) + g.nchunks];
-  const int32_t *__restrict__ pos_of = ORDERED ? o.pos_of + (int64_t)set * cap : nullptr;
-  // the bin-order positions of a trip's features (written by phase A2 of this workgroup: only behind its barrier)
-  auto fetch_pos = [&](Coords &q) {
-#pragma unroll
-    for (int32_t h = 0; h < NF; h++) q.ps[h] = (ORDERED && !dropped && q.lives[h]) ? pos_of[base + q.fs[h]] : 0;
-  };
-  auto fetch = [&](int32_t f0, Coords &q, u32x4a1 (&prow)[NF], bool with_pos) {
+  struct Coords { int32_t fs[NF], us[NF], vs[NF], cs[NF]; bool lives[NF]; };
+  auto fetch = [&](int32_t f0, Coords &q, u32x4a1 (&prow)[NF]) {
 #pragma unroll
     for (int32_t h = 0; h < NF; h++) {
       q.fs[h] = f0 + 16 * h + grp;
       q.lives[h] = q.fs[h] < total;
-      q.ps[h] = 0;
       const uint32_t e = sList[q.lives[h] ? q.fs[h] : 0];  // dead lanes recompute feature 0 and drop the result
       q.us[h] = e & 0x3FFF; q.vs[h] = (e >> 14) & 0x3FFF; q.cs[h] = e >> 28;
       // 32-bit byte offsets from the (wave-uniform) image base: images are <= 2^28 bytes, rows < 2^14, strides
       // < 2^24.  Byte-granular: no alignment of the image or its stride is assumed.  u+8 <= W-1 for every feature.
       prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(q.vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(q.us[h] - 7)));
     }
-    if (with_pos) fetch_pos(q);
   };
   Coords qa, qb;
   u32x4a1 pa[NF], pb[NF];
-  if (total > 0) fetch(0, qa, pa, false);
+  if (total > 0) fetch(0, qa, pa);
 
   // phase A2: bin histogram + per-bin staging + row histogram, one lane per
   // feature.  Kept out of the descriptor loop below: a returning atomic inside
@@ -744,65 +729,6 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
     const int32_t vbin = s.binsize == 1 ? vv : (int32_t)__umulhi((uint32_t)vv, s.inv_binsize);
     return (c * s.ubn + min(ubin, s.ubn - 1)) * s.vbn + min(vbin, s.vbn - 1);
   };
-  if (ORDERED) {
-    if (!dropped) {  // (workgroup-uniform)
-      // Every feature of the chunk: its bin-order position = first position of the bin (bin_start) + the chunk's offset
-      // inside the bin (cbin, from the scan) + its rank among the chunk's members of the bin IN INDEX ORDER -- the
-      // order Matcher::createIndexVector appends in (matcher.cpp:194-214) -- and its slot of the (class, v) row index
-      // likewise (any order inside a row).  The rank: lanes hold consecutive features; inside a wave the members of a
-      // slot are ranked by lane (the mask of a lane's peers = AND over the slot number's bits of the ballots), and
-      // the four waves of a round take turns at the slot counters in LDS.
-      for (int32_t k = tid; k < o.nslot; k += 256) sSlot[k] = 0;
-      for (int32_t k = tid; k < 4 * ROWS_LDS; k += 256) sRow[k] = 0;
-      __syncthreads();
-      const int32_t vbf = o.vb_first[chunk], vf = o.v_first[chunk];
-      const int32_t *__restrict__ cb = o.cbin + ((int64_t)id * g.nchunks + chunk) * o.nslot;
-      const int32_t *__restrict__ cr = o.crow + ((int64_t)id * g.nchunks + chunk) * 4 * o.VROW;
-      const int32_t *__restrict__ bs = s.bin_start + (int64_t)set * (s.nbins + 1);
-      const int32_t *__restrict__ rs = s.row_start + (int64_t)set * (4 * s.H + 1);
-      int32_t *__restrict__ sidx = s.s_idx + (int64_t)set * cap;
-      uint32_t *__restrict__ suv = s.s_uv + (int64_t)set * cap;
-      int32_t *__restrict__ rpos = s.r_pos + (int64_t)set * cap;
-      int32_t *__restrict__ posw = o.pos_of + (int64_t)set * cap;
-      const uint64_t below = (1ull << (tid & 63)) - 1ull;
-      for (int32_t f0 = 0; f0 < total; f0 += 256) {  // (uniform trip count)
-        const int32_t f = f0 + tid;
-        const bool live = f < total;
-        const uint32_t e = sList[live ? f : 0];
-        const int32_t uu = (int32_t)(e & 0x3FFF) * g.scale, vv = (int32_t)((e >> 14) & 0x3FFF) * g.scale, c = e >> 28;
-        const int32_t ubin = min(s.binsize == 1 ? uu : (int32_t)__umulhi((uint32_t)uu, s.inv_binsize), s.ubn - 1);
-        const int32_t vbin = min(s.binsize == 1 ? vv : (int32_t)__umulhi((uint32_t)vv, s.inv_binsize), s.vbn - 1);
-        const int32_t cu = c * s.ubn + ubin, slot = cu * o.VB + (vbin - vbf);
-        int32_t off_bin = 0, off_row = 0, rrank = 0;
-        if (live) {  // offsets requested ahead of the ranking
-          off_bin = bs[cu * s.vbn + vbin] + cb[slot];
-          off_row = rs[c * s.H + vv] + cr[c * o.VROW + (vv - vf)];
-          rrank = atomicAdd(&sRow[c * ROWS_LDS + (vv - vf)], 1);
-        }
-        int32_t brank = 0;
-        for (int32_t w = 0; w < 4; w++) {
-          if ((tid >> 6) == w) {
-            uint64_t peers = __ballot(live);
-            for (int32_t bit = 0; bit < o.slot_bits; bit++) {
-              const uint64_t m = __ballot((slot >> bit) & 1);
-              peers &= ((slot >> bit) & 1) ? m : ~m;
-            }
-            const int32_t before = live ? sSlot[slot] : 0;
-            brank = before + (int32_t)__popcll(peers & below);
-            if (live && (peers & below) == 0) sSlot[slot] = before + (int32_t)__popcll(peers);  // (every lane of the wave has read before the first of each group writes)
-          }
-          __syncthreads();
-        }
-        if (live) {
-          const int32_t p = off_bin + brank, fi = base + f;
-          sidx[p] = fi;
-          suv[p] = (uint32_t)uu | ((uint32_t)vv << 16);
-          posw[fi] = p;
-          rpos[off_row + rrank] = p;
-        }
-      }
-    }
-  } else {
   // The bin slot of the lane's first feature is requested here, ahead of the row ranks: the two
   // returning atomics of a feature are then one round trip deep, not two.
   const bool have0 = tid < total && base + tid < cap;
@@ -842,7 +768,6 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
 #endif
     if (slot < s.stage_cap) s.stage[((int64_t)set * s.nbins + b) * s.stage_cap + slot] = make_int2(fi, rowrel);
   }
-  }  // !ORDERED
 
   VH_ETICK(3);
   // phase B: 16 lanes per feature, lane k = sample point k; NF features per lane and loop trip.
@@ -863,8 +788,6 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
   const uint32_t m_u = k == 0 ? ~0u : 0u, m_v = k == 1 ? ~0u : 0u, m_c = k == 3 ? ~0u : 0u, m_d = k >= 4 ? ~0u : 0u;
   static_assert(16 * NF * 16 * 16 <= (int)sizeof(sLoc), "the patches reuse sLoc");
   __syncthreads();  // sLoc is dead from here on
-  if (ORDERED && total > 0) fetch_pos(qa);  // (the first trip's patch rows were requested before the positions existed)
-  uint4 *__restrict__ sdesc_w = ORDERED ? (uint4 *)(s.s_desc + (int64_t)set * cap * 8) : nullptr;
   uint32_t *sPatch = (uint32_t *)sLoc + grp * (NF * 64);  // [feature of the trip][16 rows: 15 + lane 15's spare][4 dwords] of this lane group
   const int32_t rd0 = (dy + 5) * 4 + ((dx + 5) >> 2);         // first dword of the lane's window in a patch
   const uint32_t psel = 0x03020100u + (uint32_t)((dx + 5) & 3) * 0x01010101u;  // v_perm selector of its first four bytes there
@@ -922,70 +845,22 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
       const bool okf = lives[h] && fi < cap;
       if (okf && k < 12) out[(int64_t)fi * 12 + k] = (int32_t)word;
       if (okf && k == 12) fuv[fi] = (uint32_t)(u << sh) | ((uint32_t)(v << sh) << 16);
-      // the descriptor at the feature's bin-order position as well: what the searches stream
-      if (ORDERED && okf && !dropped && k >= 4 && k < 12) ((uint32_t *)sdesc_w)[(int64_t)q.ps[h] * 8 + (k - 4)] = word;
     }
   };
   // two register sets, taken in turns: a copy from "next" to "current" would have to wait for the loads
   if (total > 0) {
     for (int32_t f0 = 0;; f0 += 32 * NF) {  // all conditions are workgroup-uniform
       const bool more1 = f0 + 16 * NF < total;
-      if (more1) fetch(f0 + 16 * NF, qb, pb, true);
+      if (more1) fetch(f0 + 16 * NF, qb, pb);
       process(qa, pa);
       if (!more1) break;
       const bool more2 = f0 + 32 * NF < total;
-      if (more2) fetch(f0 + 32 * NF, qa, pa, true);
+      if (more2) fetch(f0 + 32 * NF, qa, pa);
       process(qb, pb);
       if (!more2) break;
     }
   }
   VH_ETICK(4);
-}
-
-// --------------------------------------------------------------- count_chunks
-// VhOrder: what every chunk of VH_CHUNK NMS blocks holds per (class, u-bin, v-bin) and per (class, v) row, from the
-// detector's position codes.  A chunk's counters are its own: LDS atomics, then plain stores -- no global atomic.
-// One WAVE per chunk (16 blocks per lane, all their records requested before the first is used): as a 256-thread
-// workgroup the kernel was three barrier-separated phases around one memory round trip, 8 workgroups per CU at a time.
-__global__ void __launch_bounds__(64)
-count_chunks_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec, VhSets s, VhOrder o) {
-  extern __shared__ int32_t sCnt[];  // [nslot + 4 * VROW]
-  const int32_t id = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  constexpr int BPL = VH_CHUNK / 64;
-  const uint2 *rp = reinterpret_cast<const uint2 *>(rec) + (int64_t)id * g.nblocks;
-  const int32_t blk0 = chunk * VH_CHUNK + tid * BPL;
-  uint2 cw[BPL];
-#pragma unroll
-  for (int32_t k = 0; k < BPL; k++) cw[k] = rp[min(blk0 + k, g.nblocks - 1)];
-  const int32_t nc = o.nslot + 4 * o.VROW;
-  for (int32_t k = tid; k < nc; k += 64) sCnt[k] = 0;
-  __syncthreads();
-  const int32_t n1 = g.n + 1;
-  const int32_t vbf = o.vb_first[chunk], vf = o.v_first[chunk];
-  int32_t by = blk0 / g.nbx, bx = blk0 - by * g.nbx;
-#pragma unroll
-  for (int32_t k = 0; k < BPL; k++) {
-    if (blk0 + k < g.nblocks) {
-      const int32_t u0 = bx * n1 + g.n + VH_MARGIN, v0 = by * n1 + g.n + VH_MARGIN;
-#pragma unroll
-      for (int32_t q = 0; q < 4; q++) {
-        const uint32_t w = (q < 2) ? cw[k].x : cw[k].y;
-        const uint32_t pc = (q & 1) ? (w >> 16) : (w & 0xFFFFu);
-        if (pc == VH_NO_CODE) continue;
-        const int32_t uu = (u0 + (int32_t)(pc & 63u)) * g.scale, vv = (v0 + (int32_t)(pc >> 6)) * g.scale;
-        const int32_t ubin = min(s.binsize == 1 ? uu : (int32_t)__umulhi((uint32_t)uu, s.inv_binsize), s.ubn - 1);
-        const int32_t vbin = min(s.binsize == 1 ? vv : (int32_t)__umulhi((uint32_t)vv, s.inv_binsize), s.vbn - 1);
-        atomicAdd(&sCnt[(q * s.ubn + ubin) * o.VB + (vbin - vbf)], 1);
-        atomicAdd(&sCnt[o.nslot + q * o.VROW + (vv - vf)], 1);
-      }
-    }
-    if (++bx == g.nbx) { bx = 0; by++; }
-  }
-  __syncthreads();
-  int32_t *__restrict__ cb = o.cbin + ((int64_t)id * g.nchunks + chunk) * o.nslot;
-  int32_t *__restrict__ cr = o.crow + ((int64_t)id * g.nchunks + chunk) * 4 * o.VROW;
-  for (int32_t k = tid; k < o.nslot; k += 64) cb[k] = sCnt[k];
-  for (int32_t k = tid; k < 4 * o.VROW; k += 64) cr[k] = sCnt[o.nslot + k];
 }
 
 // --------------------------------------------------------------------- planes
@@ -1059,17 +934,10 @@ void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, in
 }
 
 void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t *rec,
-                             const int32_t *chunk_count, const VhSets &s, const VhOrder &o, hipStream_t st) {
+                             const int32_t *chunk_count, const VhSets &s, hipStream_t st) {
   if (g.nblocks <= 0) return;
   dim3 grid(g.nchunks, im.S * im.ncam);
-  if (o.enabled) hipLaunchKernelGGL(emit_features_kernel<true>, grid, dim3(256), sizeof(int32_t) * (size_t)o.nslot, st, im, g, rec, chunk_count, s, o);
-  else hipLaunchKernelGGL(emit_features_kernel<false>, grid, dim3(256), 0, st, im, g, rec, chunk_count, s, o);
-}
-
-void vh_launch_count_chunks(const VhImages &im, const VhGeom &g, const uint64_t *rec, const VhSets &s, const VhOrder &o, hipStream_t st) {
-  if (g.nblocks <= 0 || !o.enabled) return;
-  dim3 grid(g.nchunks, im.S * im.ncam);
-  hipLaunchKernelGGL(count_chunks_kernel, grid, dim3(64), sizeof(int32_t) * (size_t)(o.nslot + 4 * o.VROW), st, im, g, rec, s, o);
+  hipLaunchKernelGGL(emit_features_kernel, grid, dim3(256), 0, st, im, g, rec, chunk_count, s);
 }
 
 void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,

@@ -28,8 +28,7 @@
 #include "vh_dev.h"
 #include "../../include/viso_hip.h"
 #define VH_SH_DEVICE 1
-#include "sweep_hull.h"
-#include "vh_vote.h"
+#include "vh_vote.h"  // (includes sweep_hull.h in its 16-bit-link form)
 #include <cstdlib>
 
 namespace {
@@ -138,9 +137,7 @@ __global__ __launch_bounds__(256) void vote_prep_kernel(VhVote vt, int32_t p0, c
   int4 *d = (int4 *)(vt.pm + (int64_t)p * vt.cap + i);
   d[0] = w0; d[1] = w1; d[2] = w2;
   // {u1p v1p i1p u2p | v2p i2p u1c v1c | i1c u2c v2c i2c}
-  const float u1p = __int_as_float(w0.x), v1p = __int_as_float(w0.y), u1c = __int_as_float(w1.z), v1c = __int_as_float(w1.w);
-  vt.pts[(int64_t)p * vt.cap + i] = make_float2(u1c, v1c);
-  vt.flow[(int64_t)p * vt.cap + i] = make_float2(u1c - u1p, v1c - v1p);  // remove_outliers.cpp:40-47
+  vote_pts(vt, p)[i] = make_float2(__int_as_float(w1.z), __int_as_float(w1.w));  // (u1c, v1c): the point the vote triangulates
   vt.votes[(int64_t)p * vt.cap + i] = 0;
 }
 
@@ -151,7 +148,7 @@ __global__ __launch_bounds__(64) void vote_order_kernel(VhVote vt) {
   VhVoteMeta &m = vt.meta[p];
   if (m.status != VH_VOTE_OK) return;
   const int32_t n = m.n;
-  const float2 *pts = vt.pts + (int64_t)p * vt.cap;
+  const float2 *pts = vote_pts(vt, p);
   const float inf = __builtin_inff();
   // :192-205 bounding box (std::min / std::max keep their second argument on an unordered comparison)
   float lo_x = inf, lo_y = inf, hi_x = -inf, hi_y = -inf;
@@ -170,7 +167,7 @@ __global__ __launch_bounds__(64) void vote_order_kernel(VhVote vt) {
   const float span = bw * bw + bh * bh;
   const float mid_x = (lo_x + hi_x) / 2, mid_y = (lo_y + hi_y) / 2;
   // distances from the centre: sort keys, and the first point (:207-232)
-  uint2 *buf_a = (uint2 *)(vt.half + (int64_t)p * 8 * vt.cap), *buf_b = buf_a + vt.cap;
+  uint2 *buf_a = vote_sort_buf(vt, p), *buf_b = buf_a + vt.cap;
   uint64_t best = ~0ull;
   bool plain = true;
   for (int32_t i = lane; i < n; i += 64) {
@@ -263,7 +260,7 @@ __global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes
   if (m.status != VH_VOTE_OK) return;
   vh_sh::Sweep<LdsI32> sw;
   sw.node = vt.node + (int64_t)p * vt.cap;
-  sw.half = vt.half + (int64_t)p * 8 * vt.cap;
+  sw.half = vote_half(vt, p);
   sw.bucket = (LdsI32)(sweep_lds + lane * (vt.hsize + VH_VOTE_PEND));
   sw.pend = sw.bucket + vt.hsize;
   sw.pend_cap = pend_cap;  // <= VH_VOTE_PEND, the slots the launch reserved
@@ -279,11 +276,16 @@ __global__ __launch_bounds__(64) void vote_sweep_kernel(VhVote vt, int32_t lanes
 // ---- vote_tally --------------------------------------------------------------------------------------
 // remove_outliers.cpp:36-80: every triangle votes for each of its corners once per agreeing neighbour
 __device__ __forceinline__ void tally_triangle(const VhVote &vt, int32_t p, int32_t t, int32_t &a, int32_t &b, int32_t &c, int32_t &va, int32_t &vb, int32_t &vc) {
-  const vh_sh::Half *T = vt.half + ((int64_t)p * 2 * vt.cap + t) * 4;
+  const vh_sh::Half *T = vote_half(vt, p) + (int64_t)t * 3;
   const int32_t *order = vt.order + (int64_t)p * vt.cap;
   a = order[T[0].p]; b = order[T[1].p]; c = order[T[2].p];  // corner ranks -> matches
-  const float2 *flow = vt.flow + (int64_t)p * vt.cap;
-  const float2 fa = flow[a], fb = flow[b], fc = flow[c];
+  // flow vectors (u1c - u1p, v1c - v1p), remove_outliers.cpp:40-47, from the records themselves
+  const vh_p_match *pm = vt.pm + (int64_t)p * vt.cap;
+  const auto flow_of = [pm](int32_t i) {
+    const float2 prev = *(const float2 *)&pm[i].u1p, cur = *(const float2 *)&pm[i].u1c;
+    return make_float2(cur.x - prev.x, cur.y - prev.y);
+  };
+  const float2 fa = flow_of(a), fb = flow_of(b), fc = flow_of(c);
   const float tol = 5;  // hard-coded in the reference (:34), not parameters::outlier_flow_tolerance
   const int32_t ab = fabsf(fa.x - fb.x) + fabsf(fa.y - fb.y) < tol ? 1 : 0;
   const int32_t bc = fabsf(fb.x - fc.x) + fabsf(fb.y - fc.y) < tol ? 1 : 0;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(64) void vote_select_kernel(VhVote vt, int32_t max_
   const int32_t cols = (int32_t)floorf(u_max / bw) + 1, rows = (int32_t)floorf(v_max / bh) + 1;
   const int64_t nb64 = (int64_t)cols * rows;
   // the sort's ping-pong buffers in the half-edge storage (the tally is over); per bucket {start, shuffle offset, out offset}
-  uint2 *buf_a = (uint2 *)(vt.half + (int64_t)p * 8 * vt.cap), *buf_b = buf_a + vt.cap;
+  uint2 *buf_a = vote_sort_buf(vt, p), *buf_b = buf_a + vt.cap;
   int32_t *bstart = vt.bgrid + (int64_t)p * 3 * (vt.nb_max + 1);  // [nb + 1]
   if (cols < 1 || rows < 1 || nb64 > vt.nb_max) {
     if (lane == 0) { m.status = VH_VOTE_UNSUPPORTED; if (out_count) out_count[p] = 0; }

@@ -115,13 +115,13 @@ bool prepare(Scratch &w, int32_t n, int32_t seeds[3], float &span) {
   return true;
 }
 
-// triangulate w.pts[0, n): the corners of triangle t < return value are w.half[4 t + 0..2].p
+// triangulate w.pts[0, n): the corners of triangle t < return value are w.half[3 t + 0..2].p
 int32_t triangulate(Scratch &w, int32_t n) {
   if (n < 3) return 0;
   int32_t seeds[3];
   float span = 0;
   if (!prepare(w, n, seeds, span)) return 0;
-  if (w.node.size() < static_cast<size_t>(n)) { w.node.resize(n); w.half.resize(8 * static_cast<size_t>(n)); }
+  if (w.node.size() < static_cast<size_t>(n)) { w.node.resize(n); w.half.resize(6 * static_cast<size_t>(n)); }
   vh_sh::Sweep<int32_t *> sw{};
   sw.node = w.node.data(); sw.half = w.half.data();
   w.bucket.resize(static_cast<size_t>(vh_sh::hash_size(n)));
@@ -159,7 +159,7 @@ extern "C" int32_t vh_remove_outliers_pm(vh_p_match *pm, int32_t n, int32_t *n_o
     return std::fabs(au - bu) + std::fabs(av - bv) < tol ? 1 : 0;
   };
   for (int32_t t = 0; t < ntri; t++) {
-    const int32_t a = half[4 * t].p, b = half[4 * t + 1].p, c = half[4 * t + 2].p;
+    const int32_t a = half[3 * t].p, b = half[3 * t + 1].p, c = half[3 * t + 2].p;
     const int32_t ab = flow_agrees(a, b), bc = flow_agrees(b, c), ac = flow_agrees(a, c);
     votes[a] += ab + ac;
     votes[b] += ab + bc;

@@ -32,25 +32,46 @@
 #endif
 
 namespace vh_sh {
+// (the two builds of this header live in one shared library: the inline namespace keeps their symbols apart)
+#ifdef VH_SH_LINK16
+inline namespace link16 {
+#else
+inline namespace link32 {
+#endif
 
 constexpr int32_t kNone = -1;  // the reference's INVALID_INDEX (delaunator.cpp:13); ids are non-negative
 
 struct Pt { float x, y; };
 
-struct alignas(32) Node {  // one per point, valid from the point's insertion on
+// Hull links are point indices.  The device build (VH_SH_LINK16: lists of at most 65 535 points) keeps them in 16 bits,
+// which makes a node 16 bytes -- one aligned load, four nodes per 64-byte sector instead of two.
+#ifdef VH_SH_LINK16
+typedef uint16_t link_t;
+struct alignas(16) Node {  // one per point, valid from the point's insertion on
+#else
+typedef int32_t link_t;
+struct alignas(4) Node {
+#endif
   float x, y;
-  int32_t next, prev;  // hull links (next == own index: off the hull)
+  link_t next, prev;   // hull links (next == own index: off the hull)
   int32_t edge_of;     // half-edge of the triangle behind the hull edge node -> next
-  int32_t pad[3];
 };
+VH_SH_FN Node make_node(float x, float y, int32_t next, int32_t prev, int32_t edge_of) {
+  Node n;
+  n.x = x; n.y = y; n.next = static_cast<link_t>(next); n.prev = static_cast<link_t>(prev); n.edge_of = edge_of;
+  return n;
+}
 
 struct alignas(16) Half {  // one half-edge
   int32_t p;     // corner it starts at
   float x, y;    // that corner's point
   int32_t twin;  // the same edge seen from the neighbouring triangle (kNone: hull)
 };
+// Half-edge ids are 4 t + k (k = 0..2) so that next / previous are two instructions; in MEMORY a triangle is three
+// consecutive records, 48 bytes (round 4 stored four slots per triangle: a third more footprint and traffic for nothing).
 VH_SH_FN int32_t next_half(int32_t h) { return (h & 3) == 2 ? h - 2 : h + 1; }
 VH_SH_FN int32_t prev_half(int32_t h) { return (h & 3) == 0 ? h + 2 : h - 1; }
+VH_SH_FN int32_t half_slot(int32_t h) { return (h >> 2) * 3 + (h & 3); }
 
 // orientation test of delaunator.cpp:99-121 (the `clockwise` twin is unused there)
 VH_SH_FN bool turns_ccw(Pt p, Pt q, Pt r) {
@@ -102,8 +123,8 @@ VH_SH_FN int32_t hash_size(int32_t n) {
 // FastI32: pointer to int32 for the angular hash and the flip stack (host: int32_t *; device: an LDS pointer)
 template <class FastI32>
 struct Sweep {
-  // storage (caller-owned): node[n], half[8 n] (a triangulation of n points has fewer than 2 n triangles,
-  // four record slots each), bucket[hash_size(n)], pend[pend_cap]
+  // storage (caller-owned): node[n], half[6 n] (a triangulation of n points has fewer than 2 n triangles,
+  // three records each: half_slot), bucket[hash_size(n)], pend[pend_cap]
   Node *node;
   Half *half;
   FastI32 bucket;
@@ -128,6 +149,8 @@ struct Sweep {
   int64_t st_fix = 0, st_fix_steps = 0, st_flips = 0, st_legal_iters = 0, st_walk = 0, st_pop_miss = 0;
 #endif
 
+  VH_SH_FN Half &hf(int32_t h) const { return half[half_slot(h)]; }
+
   // delaunator.cpp:178-182 + :551-557
   VH_SH_FN int32_t bucket_of(Pt q) const {
     const float dx = q.x - origin.x, dy = q.y - origin.y;
@@ -143,10 +166,11 @@ struct Sweep {
   VH_SH_FN int32_t emit(int32_t i0, Pt P0, int32_t i1, Pt P1, int32_t i2, Pt P2, int32_t a, int32_t b, int32_t c, Half &H0, Half &H1, Half &H2) {
     const int32_t h = 4 * ntri++;
     H0 = Half{i0, P0.x, P0.y, a}; H1 = Half{i1, P1.x, P1.y, b}; H2 = Half{i2, P2.x, P2.y, c};
-    half[h] = H0; half[h + 1] = H1; half[h + 2] = H2;
-    if (a != kNone) half[a].twin = h;
-    if (b != kNone) half[b].twin = h + 1;
-    if (c != kNone) half[c].twin = h + 2;
+    Half *T = half + 3 * (h >> 2);
+    T[0] = H0; T[1] = H1; T[2] = H2;
+    if (a != kNone) hf(a).twin = h;
+    if (b != kNone) hf(b).twin = h + 1;
+    if (c != kNone) hf(c).twin = h + 2;
     return h;
   }
 
@@ -180,7 +204,7 @@ struct Sweep {
       bool flipped = false;
       if (b != kNone) {
         const int32_t bl = prev_half(b);
-        Half Hbl = half[bl];
+        Half Hbl = hf(bl);
         if (inside_circumcircle(Pt{Har.x, Har.y}, Pt{Ha.x, Ha.y}, Pt{Hal.x, Hal.y}, Pt{Hbl.x, Hbl.y})) {
 #ifdef VH_SH_STATS
           st_flips++;
@@ -189,13 +213,13 @@ struct Sweep {
           const int32_t outer = Hbl.twin, har = Har.twin, ar = prev_half(a), br = next_half(b);
           if (outer == kNone) hull_fix(bl, a);
           Ha = Half{Hbl.p, Hbl.x, Hbl.y, outer};
-          half[a] = Ha;
-          if (outer != kNone) half[outer].twin = a;
+          hf(a) = Ha;
+          if (outer != kNone) hf(outer).twin = a;
           const Half Hb{Har.p, Har.x, Har.y, har};
-          half[b] = Hb;
-          if (har != kNone) half[har].twin = b;
-          Har.twin = bl; half[ar].twin = bl;
-          Hbl.twin = ar; half[bl].twin = ar;
+          hf(b) = Hb;
+          if (har != kNone) hf(har).twin = b;
+          Har.twin = bl; hf(ar).twin = bl;
+          Hbl.twin = ar; hf(bl).twin = ar;
           // push b0 + (b + 1) % 3
           if (depth > 0) {
             if (depth - 1 < pend_cap) pend[depth - 1] = top;
@@ -211,7 +235,7 @@ struct Sweep {
           top = br;
           depth++;
           if (depth > max_depth) max_depth = depth;
-          cb = br; Cs = half[br]; Cn = Hbl; Cp = Hb;  // (nothing is written between here and the moment br is taken off the stack, unless another flip replaces these)
+          cb = br; Cs = hf(br); Cn = Hbl; Cp = Hb;  // (nothing is written between here and the moment br is taken off the stack, unless another flip replaces these)
           flipped = true;  // and look at edge a again
         }
       }
@@ -225,7 +249,7 @@ struct Sweep {
 #ifdef VH_SH_STATS
           st_pop_miss++;
 #endif
-          Ha = half[a]; Hal = half[next_half(a)]; Har = half[prev_half(a)];
+          Ha = hf(a); Hal = hf(next_half(a)); Har = hf(prev_half(a));
         }
         cb = kNone;
       }
@@ -259,9 +283,9 @@ struct Sweep {
     buckets = hash_size(n);
     for (int32_t k = 0; k < buckets; k++) bucket[k] = kNone;
     hull_entry = s0;
-    node[s0] = Node{P0.x, P0.y, s1, s2, 0, {0, 0, 0}};
-    node[s1] = Node{P1.x, P1.y, s2, s0, 1, {0, 0, 0}};
-    node[s2] = Node{P2.x, P2.y, s0, s1, 2, {0, 0, 0}};
+    node[s0] = make_node(P0.x, P0.y, s1, s2, 0);
+    node[s1] = make_node(P1.x, P1.y, s2, s0, 1);
+    node[s2] = make_node(P2.x, P2.y, s0, s1, 2);
     bucket[bucket_of(P0)] = s0;
     bucket[bucket_of(P1)] = s1;
     bucket[bucket_of(P2)] = s2;
@@ -326,7 +350,7 @@ struct Sweep {
         t = emit(fwd, Pt{FW.x, FW.y}, i, q, f2, Pt{F2.x, F2.y}, edge_i, kNone, eo_fwd, H0, H1, H2);
         edge_i = legalize(t + 2, H2, H0, H1);
         if (overflow) return;
-        node[fwd].next = fwd;  // off the hull
+        node[fwd].next = static_cast<link_t>(fwd);  // off the hull
         fwd = f2;
         FW = F2;
       }
@@ -340,19 +364,20 @@ struct Sweep {
           legalize(t + 2, H2, H0, H1);
           if (overflow) return;
           node[b].edge_of = t;
-          node[e].next = e;
+          node[e].next = static_cast<link_t>(e);
           e = b;
           E = Bn;
         }
       }
-      node[i] = Node{q.x, q.y, fwd, e, edge_i, {0, 0, 0}};
+      node[i] = make_node(q.x, q.y, fwd, e, edge_i);
       hull_entry = e;
-      node[fwd].prev = i;
-      node[e].next = i;
+      node[fwd].prev = static_cast<link_t>(i);
+      node[e].next = static_cast<link_t>(i);
       bucket[first] = i;
       bucket[bucket_of(Pt{E.x, E.y})] = e;
     }
   }
 };
 
+}  // inline namespace
 }  // namespace vh_sh

@@ -97,13 +97,12 @@ struct VhSets {
   int32_t *row_hist;   // [set][4*H]
   int32_t *row_cursor; // [set][4*H]
   int32_t *r_pos;      // [set][cap] bin-order position of the feature at each row-order position
-  int4 *tiles;       // [set][max_tiles] {q0, q1, class, ub}
+  int4 *tiles;       // [set][max_tiles] {first snake index, end, class, column of the first} (kernels_bin.hip: make_tiles)
   int32_t *tile_cnt; // [set]
   int32_t cap, nbins, ubn, vbn, binsize, max_tiles;
   uint32_t inv_binsize;  // ceil(2^32 / binsize): x / binsize == __umulhi(x, inv_binsize) for 0 <= x < 2^18
   int32_t W, H;      // dims_c of the matcher (full resolution)
   int32_t stage_cap;   // max features of one class in one bin for features of this detector (geometry bound)
-  int32_t tile_span; // bins per tile group: vbn (one (class,u-bin) column) or ubn*vbn (a whole class)
   uint32_t *check;   // [4] -DVH_CHECK builds: {violations, code of the first, its value, its bound}; unused otherwise
 };
 
@@ -128,31 +127,6 @@ struct VhSets {
 #else
 #define VH_CHECK_RANGE(s_, code_, x_, lo_, hi_) do { } while (0)
 #endif
-
-// Bin-ordered emission of the detector's features (count_chunks / bin_scan_ordered / emit_features<true>):
-// every chunk of VH_CHUNK NMS blocks counts its features per (class, u-bin, v-bin) and per (class, v) row,
-// the scan turns the counts into the offset of the chunk's first member inside its bin / row, and the
-// emission writes every feature straight to its final bin-order position -- in index order inside a bin,
-// because a chunk's members are ranked in index order and chunks follow each other in index order.
-// No staging, no sort, no global atomic per feature.  Geometry limits (engine.hip: setup_order) decide
-// whether a group uses it; caller-supplied feature sets keep the histogram / fill / sort kernels.
-#define VH_ORDER_SLOTS_MAX 2048  // (class, u-bin, v-bin of the chunk) counters per chunk
-#define VH_ORDER_ROWS_MAX 64     // pixel rows a chunk's features may span
-struct VhOrder {
-  int32_t enabled;
-  int32_t VB;        // v-bins a chunk can touch
-  int32_t VROW;      // full-resolution pixel rows a chunk's features can span
-  int32_t nslot;     // 4 * ubn * VB
-  int32_t slot_bits; // bits of a slot number
-  const int32_t *vb_first;  // [nchunks] first v-bin of chunk k
-  const int32_t *v_first;   // [nchunks] smallest full-resolution v of a feature of chunk k
-  const int32_t *bin_k0, *bin_k1;  // [vbn] chunks [k0, k1] that can hold features of v-bin vb
-  const int32_t *row_k0, *row_k1;  // [H]   chunks that can hold features of pixel row v
-  int32_t *cbin;     // [image][nchunks][nslot]    count -> offset of the chunk's first member inside its bin
-  int32_t *crow;     // [image][nchunks][4 * VROW] count -> offset inside the (class, v) row
-  int32_t *cbase;    // [image][nchunks + 1]       index of the chunk's first feature; [nchunks]: first chunk dropped for capacity
-  int32_t *pos_of;   // [set][cap] bin-order position of every feature (index order)
-};
 
 struct VhPass {
   int32_t qset;  // role (VH_SET_*) providing the queries
@@ -203,16 +177,11 @@ void vh_launch_half_res(const VhImages &src, uint8_t *dst, const VhGeom &g, hipS
 void vh_launch_detect_nms(const VhImages &im, const VhGeom &g, uint64_t *rec, int32_t *chunk_count,
                           hipStream_t st);
 void vh_launch_emit_features(const VhImages &im, const VhGeom &g, const uint64_t *rec,
-                             const int32_t *chunk_count, const VhSets &s, const VhOrder &o, hipStream_t st);
-// (o is positioned at the launch's first image, like rec and chunk_count)
-void vh_launch_count_chunks(const VhImages &im, const VhGeom &g, const uint64_t *rec, const VhSets &s, const VhOrder &o, hipStream_t st);
-void vh_launch_bin_scan_ordered(const VhImages &im, const VhGeom &g, const int32_t *chunk_count, const VhSets &s, const VhOrder &o,
-                                int32_t set0, int32_t nsets, hipStream_t st);
+                             const int32_t *chunk_count, const VhSets &s, hipStream_t st);
 void vh_launch_planes(const uint8_t *img, int32_t bpl, int32_t H, uint8_t *du, uint8_t *dv,
                       int16_t *f1, int16_t *f2, hipStream_t st);
 
-void vh_launch_zero_counters(const VhSets &s, int32_t set0, int32_t nsets, int32_t *extra, int64_t n_extra, int32_t light,
-                             hipStream_t st);
+void vh_launch_zero_counters(const VhSets &s, int32_t set0, int32_t nsets, int32_t *extra, int64_t n_extra, hipStream_t st);
 void vh_launch_bin_hist(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
 void vh_launch_bin_scan(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);
 void vh_launch_bin_fill(const VhSets &s, int32_t set0, int32_t nsets, hipStream_t st);

@@ -404,6 +404,12 @@ int32_t vh_group_estimate_motion_mono(vh_group *g, const vh_mono_params *e, cons
  *                         matcher's own kernels; lanes_per_wave (1..64) lists share a wavefront.  Default 64, 3, 16 (a batch takes
  *                         0.4-0.5 s whatever its size: the rate is steps in flight over that latency).
  *                         VH_ERR_STATE while steps are in flight.
+ *                         Device memory of the ring: batches * steps_per_batch * S lists, each 176 bytes per record slot
+ *                         (cap_per_stream slots: the record, its point, votes, order, a 16-byte hull node, six 16-byte
+ *                         half-edge records) + 48 bytes per bucketed output record + the estimator's scratch -- 2.0 MB per
+ *                         KITTI list of 11 363 slots.  The first vh_group_post_begin_device sizes the ring against the
+ *                         device's free memory: steps_per_batch is halved until the ring fits 80 % of it, and
+ *                         VH_ERR_CAPACITY is returned -- before anything has moved -- if one step per batch does not.
  *   vh_group_post_begin_device   after vh_group_match_features: the step's S lists leave the matcher's buffer for the
  *                         current batch (a device-to-device move; the matcher can go on at once); a full batch is launched:
  *                         vote -> Matcher::bucketFeatures(max_features, bucket_width, bucket_height) (bucket sides >= 1 px)
@@ -415,7 +421,10 @@ int32_t vh_group_estimate_motion_mono(vh_group *g, const vh_mono_params *e, cons
  *                         bucketed[S][cap_per_stream] (nullable; needs want_lists) as vh_group_post_finish.  A caller that
  *                         finishes step t - steps_per_batch * (batches - 1) after beginning step t never waits for the vote.
  *                         Every step begun must be finished before the ring of steps_per_batch * batches steps comes
- *                         round (VH_ERR_STATE from the begin call otherwise).
+ *                         round (VH_ERR_STATE from the begin call otherwise).  A stream whose list was refused
+ *                         (truncated: VH_ERR_CAPACITY; NaN / negative coordinates or an exhausted flip stack:
+ *                         VH_ERR_UNSUPPORTED) reports ok = 0, n_inliers = 0, tr = 0, counts = -1; the other streams of
+ *                         the step are delivered as usual and the call returns the error code.
  * Results per stream are those of vh_group_post_finish: lists and flags bit for bit, tr to rounding. */
 int32_t vh_group_post_device_config(vh_group *g, int32_t steps_per_batch, int32_t batches, int32_t lanes_per_wave);
 int32_t vh_group_post_begin_device(vh_group *g, int32_t cap_per_stream, int32_t max_features, float bucket_width, float bucket_height,

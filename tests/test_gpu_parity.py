@@ -599,7 +599,7 @@ def test_index_invariants_on_the_checking_build(pkg, gpu):
     import subprocess, sys
     assert os.path.exists(pkg.CHECK_LIB_PATH), "build() makes it"
     env = dict(os.environ, VISO_HIP_LIB=pkg.CHECK_LIB_PATH)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "not checking_build and not bin_ordered"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "not checking_build"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "VH_CHECK" not in r.stderr
@@ -650,19 +650,6 @@ def test_quad_matching_with_motion_prior(pkg, ob, oracle, gpu):
     g.matchFeaturesPrior(pkg.METHOD_QUAD, np.stack([trs[1], trs[0]]))
     assert g.getMatches(0).tobytes() == want[0][1].tobytes() and g.getMatches(1).tobytes() == want[1][0].tobytes()
     g.close()
-
-
-@pytest.mark.gpu
-def test_bin_ordered_emission_path(pkg, gpu):
-    """VH_ORDER=1: the detector's features go straight to their bin-order positions (count_chunks -> scan -> emission;
-    csrc/vh_dev.h VhOrder) instead of through per-bin staging and bin_sort.  Same results, bit for bit: every other test of
-    this file on that path (the default path is the other one, on measurement: profiles/EXPERIMENTS.md)."""
-    import subprocess, sys
-    env = dict(os.environ, VH_ORDER="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                        "not checking_build and not bin_ordered"], env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
 
 
 @pytest.mark.gpu

@@ -503,6 +503,11 @@ def test_gpu_device_post_stage_matches_the_oracle_chain(steps_per_batch, batches
     with pytest.raises(pkg.VisoHipError) as ex:
         g.postFinishDevice(0)
     assert ex.value.code == pkg.VH_ERR_CAPACITY
+    # ... per stream: a refused list reports counts = -1, ok = 0 (the healthy streams of a step are still delivered)
+    g.matchFeatures(pkg.METHOD_QUAD)
+    g.postBeginDevice(16, 2, 50.0, 50.0, ego=ge, rand3=raw[0])
+    r = g.postFinishDevice(0, strict=False)
+    assert r["rc"] == pkg.VH_ERR_CAPACITY and (r["counts"] == -1).all() and not r["ok"].any() and not r["tr"].any()
     g.close()
 
 
