@@ -1088,7 +1088,7 @@ struct Group {
 
   int32_t post_device_config(int32_t steps_per_batch, int32_t batches, int32_t lanes) {
     if (steps_per_batch < 1 || steps_per_batch > 256 || batches < 1 || batches > 64 || lanes < 1 || lanes > 64) return VH_ERR_INVALID_ARG;
-    for (auto &b : vbatch) if (b.busy || b.steps) return VH_ERR_STATE;  // steps in flight
+    for (auto &b : vbatch) if (b.busy) return VH_ERR_STATE;  // steps begun whose results have not been handed out
     vote_release();
     vote_steps = steps_per_batch; vote_batches = batches; vote_lanes = lanes;
     return VH_OK;

@@ -118,7 +118,7 @@ __device__ __forceinline__ int32_t scan_exclusive(int32_t n, int32_t *sWave, Loa
 // the lanes of every wave are filled (only the last tile of a class is partial) AND a tile that runs from the end of
 // one column into the next stays compact: it holds the bottoms (or the tops) of two neighbouring columns.  Tiles cut
 // at column ends instead leave ~10 % of the lanes idle; tiles over plain bin order make every crossing tile span the
-// whole image height (tools/tile_model.py: evaluated / in-window pairs 1.40 / 1.38 / 1.32 at KITTI size).
+// whole image height (tools/tile_model3.py: evaluated / in-window pairs 1.40 / 1.38 / 1.32 at KITTI size).
 // A tile record is {first snake index, end, class, column of the first index}; a snake index k inside column
 // [A, B) of the bin order is the position k (even column) or A + B - 1 - k (odd column): kernels_match.hip.
 // One lane per (class, column) writes the tiles that start inside its column.

@@ -145,6 +145,33 @@ def test_random_configs_vs_oracle(trial, pkg, ob, oracle, gpu):
         assert got.tobytes() == want.tobytes(), (over, method)
 
 
+@pytest.mark.parametrize("binsize,tau", [(2, 70), (3, 80), (4, 80)])
+def test_query_tiles_across_many_sparse_columns(binsize, tau, pkg, ob, oracle, gpu):
+    """Snake-ordered query tiles (csrc/kernels_bin.hip: make_tiles) on sets with far fewer features than (class, u-bin)
+    columns: a tile of 32 queries then runs through dozens of columns -- more than the 63 column starts a wave holds at a
+    time for the snake index -> position mapping (kernels_match.hip: flow_tile), so the table is re-fetched mid-tile -- and
+    through empty ones.  Caller-supplied feature sets (histogram / fill / sort path) and the detector's own."""
+    W, H = 1400, 120
+    over = {"nms_tau": tau, "match_binsize": binsize, "match_radius": 150}
+    p, po = pkg.Params.default(**over), ob.Params.default(**over)
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    imgs = [pkg.synth.frame(W, H, dx, dy, 9, 1, 77) for dx, dy in ((0, 0), (9, 0), (4, 1), (13, 1))]
+    f = feats_for(oracle, po, dims, imgs)
+    ncol = -(-W // binsize)
+    per_class = [int((f[0][:, 3] == c).sum()) for c in range(4)]
+    assert 0 < min(per_class) and max(per_class) * 2 < ncol, (per_class, ncol)  # (sparse: a 32-query tile spans > 64 columns on average)
+    for flow in (True, False):
+        assert np.array_equal(pkg.match_all(p, dims, f[2], f[0], flow=flow), oracle.match_all(po, dims, f[2], f[0], flow=flow))
+    for method in (0, 1, 2):
+        assert pkg.match(p, dims, method, *f).tobytes() == oracle.matching(po, dims, method, *f).tobytes(), method
+    m = pkg.Matcher(p, outlier_removal=False)
+    m.pushBack(imgs[0], imgs[1], dims, False)
+    m.pushBack(imgs[2], imgs[3], dims, False)
+    m.matchFeatures(pkg.METHOD_QUAD)
+    assert m.getMatches().tobytes() == oracle.matching(po, dims, 2, *f).tobytes()
+    m.close()
+
+
 # ------------------------------------------------ stateful Matcher: ring buffer, methods
 def test_matcher_ring_buffer_and_methods(pkg, ob, oracle, gpu):
     """pushBack ring (src/matcher.cpp:64-79), replace flag, stereo + quad + flow on one handle."""
