@@ -8,14 +8,17 @@
 //    is a pure function of (query feature, candidate set), so here every pass
 //    of a chain is evaluated for ALL features of its query set at once
 //    (`match`), and the chains are then followed by table look-ups (`chain`).
-//  * Mapping (flow_tile / rows_tile below): one wavefront per tile of <= 32 consecutive
-//    bin-ordered queries of one class (row-ordered for the 1-d stereo passes).  The 64 lanes are
+//  * Mapping (flow_tile / rows_tile below): one wavefront per tile of <= 32 consecutive queries
+//    of one class -- in SNAKE order over the (class, u-bin) columns for the flow passes
+//    (kernels_bin.hip: make_tiles; the queries' order is free, only the candidates' positions carry
+//    the tie-break), in (class, v) row order for the 1-d stereo passes.  The 64 lanes are
 //    4 phases of 16 lanes, lane (phase, l) holds queries l and l+16, so every phase holds the
 //    whole tile; the candidate region of the tile -- the union of its queries' bin ranges -- is
-//    streamed through a wave-private LDS chunk of 64 candidates, and the four phases take
-//    candidates j, j+1, j+2, j+3 of it in the same step: one candidate stream shared by all
-//    phases, every record read from LDS serves two queries per lane, 8 v_sad_u8 / v_sad_hi_u8 per
-//    pair, the partial minima joined by two shuffles per tile.
+//    streamed through two wave-private LDS buffers of 64 candidates filled by LDS-DMA
+//    (walk_region_lds), and the four phases take candidates j, j+1, j+2, j+3 of a buffer in the
+//    same step: one candidate stream shared by all phases, every record read from LDS serves two
+//    queries per lane, 8 v_sad_u8 / v_sad_hi_u8 per pair, the partial minima joined by two
+//    shuffles per tile.
 //    Positions in bin order ARE the reference's visiting order, so its first-minimum tie-break
 //    (strict `<`, src/matcher.cpp:264) is the minimum of the key (SAD << 19 | position) -- or
 //    (SAD << 16 | position - class base), which the v_sad_hi_u8 chain produces by itself --
@@ -479,7 +482,7 @@ __device__ __forceinline__ void finish_tile(const VhSets &s, const VhMatchArgs &
 
 // One tile of the flow search.
 //
-// A tile is T = 64*Q/P consecutive bin-ordered queries of one class.  The wave's
+// A tile is T = 64*Q/P consecutive queries of one class in snake order.  The wave's
 // 64 lanes are P *phases* of L = 64/P lanes; lane (phase, l) holds the Q queries
 // l, l+L, .. of the tile, so every phase holds the whole tile, and the P phases
 // take the candidates j, j+1, .., j+P-1 of the staged chunk in the same step:
@@ -488,7 +491,7 @@ __device__ __forceinline__ void finish_tile(const VhSets &s, const VhMatchArgs &
 // (round 1: T = 64, P = 1, Q = 1):
 //  * a 16- or 32-query tile is compact (about one 50x50 bin), so the union of its
 //    lanes' windows exceeds each lane's own window by less: fewer evaluated pairs
-//    outside the window (tools/tile_model2.py, tools/flow_stats.py);
+//    outside the window (tools/tile_model3.py, tools/flow_stats.py);
 //  * with Q = 2 every candidate record read from LDS serves two queries per
 //    lane.  The record reads (4 LDS cycles per ds_read_b128 and wave, four SIMDs
 //    sharing one LDS array) otherwise saturate the LDS beside 8 v_sad_u8 per

@@ -14,3 +14,4 @@ python tools/ego_timing.py > gpurun_out/${TAG}_ego_timing.txt 2>&1; tail -2 gpur
 python tools/latency_one.py > gpurun_out/${TAG}_latency_one.txt 2>&1; tail -1 gpurun_out/${TAG}_latency_one.txt
 for fr in 0.05 0.2; do python bench.py --noise 1 --noise-frac $fr --cpu-seconds 4 --no-e2e > gpurun_out/${TAG}_ctx_noise1_frac$fr.json 2> gpurun_out/${TAG}_ctx_noise1_frac$fr.err || tail -3 gpurun_out/${TAG}_ctx_noise1_frac$fr.err; echo "ctx noise 1 frac $fr done"; done
 tools/mono_kernels.sh 256 > /dev/null 2>&1; cp gpurun_out/mono_kernels.txt gpurun_out/${TAG}_mono_kernels.txt; tail -12 gpurun_out/${TAG}_mono_kernels.txt
+timeout 200 python tools/fuzz_vote.py --seconds 90 --seed 55 > gpurun_out/${TAG}_fuzz_vote.txt 2>&1; tail -2 gpurun_out/${TAG}_fuzz_vote.txt
