@@ -287,11 +287,11 @@ def dist_selftest(args):
     proto.close()
 
 
-def context_workload(pkg, torch, dev, local_rank, name, noise, ob=None, steps=12, blocks=3, warmup=6):
+def context_workload(pkg, torch, dev, local_rank, name, noise, ob=None, steps=40, blocks=1, warmup=8):
     """A short run of another BASELINE.json config (or of the KITTI config with sensor noise) for the default line's
-    `other_workloads` key: 12 steps x 3 blocks (the median block), the search kernel's share of the HBM yardstick from HIP
-    events, and stream 0's last step checked against the oracle.  Context, never `value`; a block this short still pays
-    the pipeline's fill (the full-length runs of the same workloads, `--workload` / `--noise`, are 3-5 % faster)."""
+    `other_workloads` key: one block of 40 steps (three blocks of 12 paid the pipeline's fill three times: 15.3 k instead of
+    18.5 k pairs/s at 1080p), the search kernel's share of the HBM yardstick from HIP events, and stream 0's last step
+    checked against the oracle.  Context, never `value`; the full-length runs of the same workloads are `--workload` / `--noise`."""
     wl = WORKLOADS[name]
     w, h, S, T = wl["W"], wl["H"], wl["streams"], 3
     t_all = time.perf_counter()
