@@ -638,7 +638,8 @@ def test_quad_matching_with_motion_prior(pkg, ob, oracle, gpu):
     findMatch's prediction term (test_find_match_prior_term).  The composition -- stock libviso2 predicts the position
     in the current right image from the (1p, 2p) pair and Tr_delta and searches hop 2 of the quad circle around it --
     is [upstream-recollection], restated in oracle/viso_oracle.c: vo_matching_quad_prior; the GPU is bit-exact against
-    that, for a single matcher and for a group with a different motion per stream.  Without a Tr_delta nothing changes."""
+    that, for a single matcher and for a group with a different motion per stream.  Without a Tr_delta nothing changes.
+    PARITY UNPINNED: this is an oracle-vs-device test, not a reference fixture -- the reference has no code to generate one."""
     W, H, S = 480, 200, 2
     dims = [W, H, pkg.synth.bytes_per_line(W)]
     K = dict(f=400.0, cu=W / 2.0, cv=H / 2.0, base=0.5)
