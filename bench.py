@@ -420,6 +420,12 @@ def main():
     if args.dist_selftest:
         return dist_selftest(args)
 
+    # ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A stream group owns five streams
+    # (+ four for the device post stage): with a second group in the process -- the context runs of `other_workloads` beside
+    # the idle KITTI group -- streams that should overlap share a queue and the second group runs 16 % slower (1080p: 15.4 k
+    # instead of 18.4 k pairs/s; the headline itself: 107.1 -> 107.7 k).  Read when HIP initialises: set before torch is imported.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
     # Rank 0 prints ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at
     # initialisation): the process's fd 1 is pointed at stderr for the run, the line goes to the saved descriptor.
     sys.stdout.flush()
@@ -770,6 +776,7 @@ def main():
             "ranks_seen": ranks_seen,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["label"] + (f" + noise +-{NOISE}" if NOISE else ""), "noise": NOISE,
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "streams_per_gpu": S, "frames_in_hbm": T, "features_per_image": float(nfm.mean()),
                        "matches_per_pair": float(nm.mean()), "parallelism": f"{world}x independent stream groups",
                        "device_mib_per_stream": round(grp.deviceBytes() / S / 2**20, 2)},
