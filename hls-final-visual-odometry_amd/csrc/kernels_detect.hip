@@ -699,7 +699,11 @@ emit_features_kernel(VhImages im, VhGeom g, const uint64_t *__restrict__ rec,
       q.us[h] = e & 0x3FFF; q.vs[h] = (e >> 14) & 0x3FFF; q.cs[h] = e >> 28;
       // 32-bit byte offsets from the (wave-uniform) image base: images are <= 2^28 bytes, rows < 2^14, strides
       // < 2^24.  Byte-granular: no alignment of the image or its stride is assumed.  u+8 <= W-1 for every feature.
+#ifdef VH_EXP_NOPATCH  // timing-only build: the descriptor's instructions without its patch gathers (descriptors are wrong)
+      prow[h] = u32x4a1{(uint32_t)q.us[h], (uint32_t)q.vs[h], 0u, 0u};
+#else
       prow[h] = *(const u32x4a1 *)(I + (__umul24((uint32_t)(q.vs[h] + prk), (uint32_t)g.bplm) + (uint32_t)(q.us[h] - 7)));
+#endif
     }
   };
   Coords qa, qb;
