@@ -558,6 +558,66 @@ def test_device_post_stage_ring_discipline(pkg, ob, oracle, gpu):
 
 
 @pytest.mark.gpu
+def test_device_post_stage_ring_is_sized_against_free_memory(pkg, ob, oracle, gpu):
+    """The ring of batches is allocated lazily, so the FIRST begin call sizes it against the device's free memory
+    (csrc/engine.hip: post_begin_device): steps per batch are halved until `batches` batches fit 80 % of it, and when even
+    one step per batch does not fit the call returns VH_ERR_CAPACITY before anything has moved -- the step's lists are
+    still in the matcher's buffer and a smaller shape goes through."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself is linked against (no second runtime in the process)
+
+    def mem_free():
+        fr, to = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(fr), C.byref(to)) == 0
+        return fr.value
+    S, W, H = 2, 320, 160
+    dims = [W, H, pkg.synth.bytes_per_line(W)]
+    seqs = [pkg.synth.stereo_sequence(W, H, 2, disparity=5 + s, blur=4, seed=700 + s) for s in range(S)]
+    po = ob.Params.default()
+    F = [[[oracle.compute_features(po, im, dims)[1] for im in seqs[s][t]] for t in range(2)] for s in range(S)]
+    want = [oracle.bucket_features(oracle.remove_outliers(oracle.matching(po, dims, 2, F[s][0][0], F[s][0][1], F[s][1][0], F[s][1][1]))[0], 2, 50, 50)
+            for s in range(S)]
+    g = pkg.StreamGroup(S, pkg.Params.default(), max_features=65535, max_matches=65535)  # (cap_per_stream is clamped to the match capacity)
+    for t in range(2):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+    g.matchFeatures(pkg.METHOD_QUAD)
+    slot = 176 * 65535 * S  # bytes per step of the ring at the largest list capacity (include/viso_hip.h states the formula)
+    # (a) 256 steps x 64 batches would be 256 * 64 * 23 MB = 378 GB: the library halves the steps until 64 batches fit
+    g.postDeviceConfig(256, 64, 1)
+    free0 = mem_free()
+    before = g.deviceBytes()
+    g.postBeginDevice(65535, 2, 50.0, 50.0, want_lists=True)
+    per_batch = g.deviceBytes() - before
+    steps = per_batch / slot
+    assert 1 <= steps < 200 and 64 * per_batch <= 0.8 * free0 * 1.02, (steps, per_batch, free0)  # (fewer than the 256 asked for)
+    assert 64 * per_batch * 2 > 0.8 * free0 * 0.9, (steps, free0)  # ... and no fewer than needed
+    r = g.postFinishDevice(0, want_lists=True, estimator=False)
+    for s in range(S):
+        assert r["lists"][s].tobytes() == want[s].tobytes()
+    g.close()
+    # (b) a device with (almost) no free memory: refused before anything moves, and a shape that fits then works
+    g = pkg.StreamGroup(S, pkg.Params.default(), max_features=65535, max_matches=65535)  # (cap_per_stream is clamped to the match capacity)
+    for t in range(2):
+        g.pushBack(np.stack([seqs[s][t][0] for s in range(S)]), np.stack([seqs[s][t][1] for s in range(S)]), dims, False)
+    g.matchFeatures(pkg.METHOD_QUAD)
+    g.postDeviceConfig(4, 64, 1)
+    hog = C.c_void_p(0)
+    assert hip.hipMalloc(C.byref(hog), C.c_size_t(mem_free() - (1 << 30))) == 0  # leaves ~1 GB: 64 batches x 1 step x 23 MB = 1.5 GB do not fit
+    try:
+        with pytest.raises(pkg.VisoHipError) as ex:
+            g.postBeginDevice(65535, 2, 50.0, 50.0, want_lists=True)
+        assert ex.value.code == pkg.VH_ERR_CAPACITY
+        g.postDeviceConfig(1, 2, 1)
+        g.postBeginDevice(4096, 2, 50.0, 50.0, want_lists=True)  # the same step: its lists never left the matcher's buffer
+        r = g.postFinishDevice(0, want_lists=True, estimator=False)
+        for s in range(S):
+            assert r["lists"][s].tobytes() == want[s].tobytes()
+    finally:
+        hip.hipFree(hog)
+        g.close()
+
+
+@pytest.mark.gpu
 def test_device_post_stage_leaves_stereo_lists_unvoted(pkg, ob, oracle, gpu):
     """Stereo records carry no previous-frame position, so removeOutliers' flow vote does not apply to them (as in the
     host form and the shim): the device post stage buckets them as they are; an estimator is refused for them."""
