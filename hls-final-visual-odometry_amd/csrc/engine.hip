@@ -93,6 +93,8 @@ struct Group {
   // with a lag of one or two steps; above 6.5 % the tested loop takes over and the speculative
   // one is probed every 16th launch, below 5.5 % it comes back.  Results never depend on the choice.
   bool stats_pending[2] = {false, false}, stats_was_spec[2] = {false, false};
+  int32_t stats_npass[2] = {0, 0};
+  int32_t tiles_hint = 0;  // query tiles per (pass, stream) row seen by an earlier launch (0: none yet)
   int32_t probe_countdown = 0, force_mode = -1;
   bool spec_mode = true;
   double last_redo_rate = -1;
@@ -207,7 +209,7 @@ struct Group {
     d_best2[0] = d_best2[1] = nullptr; d_chain2[0] = d_chain2[1] = nullptr; d_mchunk2[0] = d_mchunk2[1] = nullptr; d_redo = nullptr;
     for (int k = 0; k < 2; k++) if (h_out[k]) { (void)hipHostFree(h_out[k]); h_out[k] = nullptr; d_out_mapped[k] = nullptr; }
     if (h_matches) { (void)hipHostFree(h_matches); h_matches = nullptr; d_matches_mapped = nullptr; }
-    stats_pending[0] = stats_pending[1] = false;
+    stats_pending[0] = stats_pending[1] = false; tiles_hint = 0;
     d_mask = nullptr; d_matches = nullptr; d_match_count = nullptr; d_overflow = nullptr;
     d_ego_rand = nullptr; d_ego_ok = nullptr; d_ego_xyz = nullptr; d_ego_tr = nullptr; ego_rand_n = 0;
     d_mono_scratch = nullptr; d_mono_rand = nullptr; mono_rand_n = 0; mono_scratch_iters = 0;
@@ -547,17 +549,20 @@ struct Group {
 
   // speculative or tested search loops for the next launch (see the members above)
   bool choose_loop() {
-    if (force_mode >= 0) return force_mode == 1;
     for (int sl = 0; sl < 2; sl++) {
       if (!stats_pending[sl] || hipEventQuery(ev_post[sl]) != hipSuccess) continue;
       stats_pending[sl] = false;
       int64_t again = 0, searched = 0;
-      for (int32_t s = 0; s < S; s++) { again += h_out[sl][s].z; searched += h_out[sl][s].w; }
+      int32_t nq_max = 0;
+      for (int32_t s = 0; s < S; s++) { again += h_out[sl][s].z; searched += h_out[sl][s].w; nq_max = std::max(nq_max, h_out[sl][s].w); }
+      // query tiles the fullest stream's sets held, per pass (the searches' grid is sized by it: vh_launch_match)
+      if (stats_npass[sl] > 0) tiles_hint = nq_max / stats_npass[sl] / VH_TILE_Q + 4;
       if (!stats_was_spec[sl] || searched <= 0) continue;  // the tested loop reports nothing
       last_redo_rate = (double)again / (double)searched;
       if (spec_mode && last_redo_rate > 0.065) { spec_mode = false; probe_countdown = 16; }
       else if (!spec_mode && last_redo_rate < 0.055) spec_mode = true;
     }
+    if (force_mode >= 0) return force_mode == 1;
     if (spec_mode) return true;
     if (--probe_countdown <= 0) { probe_countdown = 16; return true; }  // probe
     return false;
@@ -574,7 +579,7 @@ struct Group {
     VH_HIP(hipStreamSynchronize(post_stream));
     for (int k = 0; k < 2; k++) VH_HIP(hipMemset(d_mchunk2[k], 0, sizeof(int32_t) * (size_t)S * ((cap + 255) / 256)));
     VH_HIP(hipMemset(d_redo, 0, sizeof(int32_t) * 2 * (size_t)S));
-    stats_pending[0] = stats_pending[1] = false;
+    stats_pending[0] = stats_pending[1] = false; tiles_hint = 0;
     last_method = -1;
     match_dirty = false;
     return VH_OK;
@@ -614,7 +619,17 @@ struct Group {
     VH_HIP(hipStreamWaitEvent(ms, ev_det[pair_prev], 0));
     if (ev_post_valid[buf]) VH_HIP(hipStreamWaitEvent(ms, ev_post[buf], 0));
     const bool spec = choose_loop();
-    { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo + (size_t)buf * S, spec ? 1 : 0, ms); }
+    // A stepped group shares the chip with its own detection chain: a grid as tight as the tiles the sets really hold, and
+    // the searches' workgroups padded to an LDS footprint that leaves the chain room on every CU (vh_launch_match has the
+    // measurements).  How many LDS allocation units (1 280 bytes) is a property of what runs beside the searches: with
+    // detect_nms<1|2> (14 units) and emit_features (21) six search workgroups of 21 units per CU are best (KITTI 107.5 ->
+    // 111.5 k, 1080p 18.5 -> 19.2 k; 20 or 22-25 units lose 2-3 % against no hint at all); with detect_nms<3> (22 units,
+    // 69 registers: the 4K configuration) five workgroups of 23-25 units (3.68 -> 4.08 k; 21 units: 3.67).  Other detectors
+    // (nms_n >= 4, the generic kernel) were not measured: no hint.  VH_MATCH_LDS_UNITS overrides (0: no hint).
+    static const int units_env = [] { const char *ev = getenv("VH_MATCH_LDS_UNITS"); return ev ? atoi(ev) : -1; }();
+    const int32_t units = units_env >= 0 ? units_env : (g.n <= 2 ? 21 : (g.n == 3 ? 24 : 0));
+    const int32_t gx_hint = (!serial && units > 0 && tiles_hint > 0) ? (tiles_hint + 3) / 4 : 0;
+    { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo + (size_t)buf * S, spec ? 1 : 0, gx_hint, units * 1280, ms); }
     VH_HIP(hipGetLastError());
     if (tr16) {  // hop 2 of the circle, per driving feature, behind the 1p -> 2p table of the launch above
       double *ht = h_prior_tr + (size_t)buf * 16 * S;
@@ -643,7 +658,7 @@ struct Group {
     { Scope sc(this, "emit_matches", ps); vh_launch_emit_matches(sets, a, method, d_chain2[buf], d_matches, mcap, d_match_count, d_overflow, d_mchunk, d_redo + (size_t)buf * S, d_mchunk2[buf ^ 1], d_out_mapped[buf], d_matches_mapped, ps); }
     VH_HIP(hipGetLastError());
     // (re-searched, searched) of this launch are read from h_out[buf] by a later choose_loop()
-    stats_pending[buf] = true; stats_was_spec[buf] = spec;
+    stats_pending[buf] = true; stats_was_spec[buf] = spec; stats_npass[buf] = a.npass;
     VH_HIP(hipEventRecord(ev_post[buf], ps)); ev_post_valid[buf] = true;
     // both slots stay in use until this point of the post stream
     VH_HIP(hipEventRecord(ev_read[pair_cur], ps)); ev_read_valid[pair_cur] = true;
@@ -1997,7 +2012,7 @@ int32_t vh_match_all(const vh_params *p, int32_t device, const int32_t dims[3], 
   if ((rc = gq->load_features(VH_SET_1P, m2, n2))) return rc;
   VhMatchArgs a = gq->match_args(VH_METHOD_FLOW);
   a.npass = 1; a.pass[0] = {VH_SET_1C, VH_SET_1P, flow ? 1 : 0, 0};
-  vh_launch_match(gq->sets, a, gq->d_best, gq->d_redo, gq->force_mode == 0 ? 0 : 1, gq->stream);
+  vh_launch_match(gq->sets, a, gq->d_best, gq->d_redo, gq->force_mode == 0 ? 0 : 1, 0, 0, gq->stream);
   VH_HIP(hipGetLastError());
   if (n1) VH_HIP(hipMemcpyAsync(best, gq->d_best, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, gq->stream));
   VH_HIP(hipStreamSynchronize(gq->stream));

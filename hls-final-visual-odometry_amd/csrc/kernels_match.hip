@@ -1117,25 +1117,38 @@ void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, dou
                            hipStream_t st) {
   hipLaunchKernelGGL(match_prior_kernel, dim3((s.cap + 127) / 128), dim3(128), 0, st, s, a, u_, v_, best);
 }
-void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, hipStream_t st) {
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, int32_t grid_x,
+                     int32_t lds_bytes, hipStream_t st) {
   if (!a.npass) return;
   VhMatchArgs m = a;
   static const int wide = [] { const char *e = getenv("VH_FLOW_WIDE_KEYS"); return e ? atoi(e) : 0; }();
   m.wide_keys = wide;
-  // One workgroup per 4 tiles of the capacity-sized tile list (the kernel loops, so any grid is
-  // correct; at typical densities 4 of 5 of these workgroups find no tile and exit at once).  The
-  // width is made odd: workgroups go to the 8 XCDs round-robin by linear id, tile k of every
-  // (pass, stream) row costs about the same, and a width that is a multiple of 8 pins tile k of
-  // all rows to one XCD (measured at KITTI size, S = 256, k pairs/s: 128 -> 85.2, 129 -> 95.6,
-  // 520 -> 91.5, 523 -> 93.5).  Tight grids make the search itself ~5 % faster (57: 1628 us vs
-  // 1700 us alone) but the STEP slower (93.1 vs 98.8): the empty workgroups dilute the search's
-  // hold on the CUs and the latency-bound kernels of the other streams run beside it; 197..263 is
-  // a plateau (99.0 / 98.8).  An LDS pad as occupancy cap instead (VH_FLOW_LDS_PAD) loses with
-  // either grid.  VH_FLOW_WGS overrides (experiments).
+  // Grid and occupancy.  The kernel loops over the tile list, so any grid is correct; what the choice decides is how the
+  // searches share the chip with the detection chain of the next frame (round 5, MI355X, KITTI, S = 256, k pairs/s):
+  //  * DEFAULT (no hint): one workgroup per 4 tiles of the capacity-sized tile list, width made odd (a multiple of 8 pins
+  //    tile k of every row to one XCD: 128 -> 85.2, 129 -> 95.6 in round 2).  At typical densities 3 of 4 of these
+  //    workgroups find no tile and leave at once; their churn is what lets the detection chain's workgroups in: 107.1-107.7.
+  //  * TIGHT (grid_x = the tiles the sets really hold / 4, from the statistics of an earlier launch) alone is worse: the
+  //    searches then hold all 7 wave slots per SIMD for their whole life, finish in 1 685 instead of 2 305 us, and the
+  //    detection chain runs on after them on an empty chip: 100.3-100.5.
+  //  * TIGHT + lds_bytes = 26 880 (21 of a CU's 128 LDS allocation units of 1 280 bytes: at most SIX search workgroups
+  //    per CU, one wave slot per SIMD and 2 units left for everybody else): **110.5-111.8**; 20 units (153 600 in six
+  //    workgroups) 104.2-105.2, 22 units (five workgroups) 104.8-105.1 -- the window is one allocation unit wide, because
+  //    it is the arithmetic of what fits beside what (detect_nms 14 units, emit_features 21), and it moves with those.
+  //    Same rule: 1080p 18.5 -> 19.2, KITTI + noise (tested loops) 73.2 -> 74.9, mono flow 140.7 -> 144.7, S = 32 / 64 /
+  //    128 streams 93.0 -> 97.8 / 102.7 -> 104.9 / 105.7 -> 105.8.  4K (detect_nms<3>: 22 units, 69 registers) wants FIVE
+  //    workgroups instead: 21 / 22 / 23 / 24 / 25 / 26 units = 3.67 / 3.94 / 4.08 / 4.08 / 4.08 / 3.96 against 3.68 -- the
+  //    caller picks the units per detector (engine.hip: match_queued).
+  // VH_FLOW_WGS / VH_FLOW_LDS_PAD override both (experiments).
   static const int wgs = [] { const char *e = getenv("VH_FLOW_WGS"); return e ? atoi(e) : 0; }();
-  const int32_t gx = wgs > 0 ? wgs : (((s.max_tiles + 3) / 4) | 1);
+  static const int pad_env = [] { const char *e = getenv("VH_FLOW_LDS_PAD"); return e ? atoi(e) : -1; }();
+  const int32_t gx = wgs > 0 ? wgs : (grid_x > 0 ? (grid_x | 1) : (((s.max_tiles + 3) / 4) | 1));
   dim3 grid(gx, m.npass, a.S);
-  static const int pad = [] { const char *e = getenv("VH_FLOW_LDS_PAD"); return e ? atoi(e) : 0; }();
+  static const size_t static_lds[2] = {
+      [] { hipFuncAttributes at{}; return hipFuncGetAttributes(&at, (const void *)match_kernel<false>) == hipSuccess ? at.sharedSizeBytes : (size_t)0; }(),
+      [] { hipFuncAttributes at{}; return hipFuncGetAttributes(&at, (const void *)match_kernel<true>) == hipSuccess ? at.sharedSizeBytes : (size_t)0; }()};
+  const size_t have = static_lds[speculative ? 1 : 0];
+  const int32_t pad = pad_env >= 0 ? pad_env : (wgs > 0 || grid_x <= 0 || lds_bytes <= 0 || have == 0 || (size_t)lds_bytes <= have ? 0 : (int32_t)((size_t)lds_bytes - have));
   if (speculative) hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), pad, st, s, m, best, redo);
   else hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), pad, st, s, m, best, redo);
 }

@@ -191,7 +191,10 @@ void vh_launch_ref_index(const VhSets &s, int32_t set, int32_t *bin_start_ref, i
 
 void vh_launch_match_prior(const VhSets &s, const VhMatchArgs &a, double u_, double v_, int32_t *best,
                            hipStream_t st);
-void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, hipStream_t st);
+// grid_x: workgroups per (pass, stream) row (<= 0: one per 4 tiles of the capacity-sized tile list); lds_bytes: LDS a workgroup
+// is to occupy, static part included (<= 0: the static part only) -- see the launcher for what both are for
+void vh_launch_match(const VhSets &s, const VhMatchArgs &a, int32_t *best, int32_t *redo, int32_t speculative, int32_t grid_x,
+                     int32_t lds_bytes, hipStream_t st);
 void vh_launch_quad_prior(const VhSets &s, const VhMatchArgs &a, const double *tr, double f, double cu, double cv, double base, int32_t *best,
                           hipStream_t st);
 // chain: [stream][cap][2] int4 = {i1p,i2p,i1c,i2c} (z = -2: no match), {uv1p,uv2p,uv1c,uv2c}
