@@ -624,10 +624,11 @@ struct Group {
     // measurements).  How many LDS allocation units (1 280 bytes) is a property of what runs beside the searches: with
     // detect_nms<1|2> (14 units) and emit_features (21) six search workgroups of 21 units per CU are best (KITTI 107.5 ->
     // 111.5 k, 1080p 18.5 -> 19.2 k; 20 or 22-25 units lose 2-3 % against no hint at all); with detect_nms<3> (22 units,
-    // 69 registers: the 4K configuration) five workgroups of 23-25 units (3.68 -> 4.08 k; 21 units: 3.67).  Other detectors
-    // (nms_n >= 4, the generic kernel) were not measured: no hint.  VH_MATCH_LDS_UNITS overrides (0: no hint).
+    // 69 registers: the 4K configuration) five workgroups of 23-25 units (3.68 -> 4.08 k; 21 units: 3.67).  KITTI frames at
+    // nms_n = 1 / 4 (detect_nms<1> 9 units, <4> 33 units): 21 units 86.0 -> 89.2 k / 106.1 -> 108.9 k, 24 units 87.7 / 105.6.
+    // The generic detector (nms_n >= 5, unaligned strides) was not measured: no hint.  VH_MATCH_LDS_UNITS overrides (0: none).
     static const int units_env = [] { const char *ev = getenv("VH_MATCH_LDS_UNITS"); return ev ? atoi(ev) : -1; }();
-    const int32_t units = units_env >= 0 ? units_env : (g.n <= 2 ? 21 : (g.n == 3 ? 24 : 0));
+    const int32_t units = units_env >= 0 ? units_env : (g.n == 3 ? 24 : (g.n <= 4 ? 21 : 0));
     const int32_t gx_hint = (!serial && units > 0 && tiles_hint > 0) ? (tiles_hint + 3) / 4 : 0;
     { Scope sc(this, "match", ms); vh_launch_match(sets, a, d_best2[buf], d_redo + (size_t)buf * S, spec ? 1 : 0, gx_hint, units * 1280, ms); }
     VH_HIP(hipGetLastError());
